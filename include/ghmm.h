@@ -1,0 +1,262 @@
+/*
+ * ghmm.h — C ABI of the MI355X-native continuous-density GMM-HMM core.
+ *
+ * This is the drop-in boundary for the diagonal-covariance hot path of
+ * edielsonpf/speech-recognition-hmm-continuous.  The reference has no library
+ * or FFI layer: its numerical core is a set of file-local C functions called
+ * from main().  Every entry point below names the reference
+ * function(s) it replaces.  Path aliases:
+ *
+ *   TF = train/source/hmm-fs/hmm_continuous_fs.c            (trainer, diagonal)
+ *   RF = test/source/recognition-fs/recognition_continuous_fs.c (recogniser, diagonal)
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns GHMM_OK (0) or an error
+ *     code and never calls exit(); ghmm_last_error() holds the detail text.
+ *   - all arithmetic on the path is IEEE double ("f64"), like the reference.
+ *   - a model is held as flat struct-of-arrays (the reference's `struct state`
+ *     TF:53-64 is array-of-structs with fixed capacity):
+ *         A[N*N] row-major, c[N*M], mean[N*M*D], inv_var[N*M*D], det[N*M]
+ *     with the reference's meaning: inv_var = 1/sigma^2 (TF:2012), det = prod
+ *     sigma^2 of the NON-inverted variances (TF:1976), exactly what a .hmm file holds.
+ *   - frames are row-major X[F][D] (F = all frames of all utterances, back to
+ *     back), i.e. the payload order of the reference's .perfil files (TF:527-544).
+ *   - per-frame outputs are frame-major: b[F][N], post[F][N*M], alpha[F][N] ...
+ *     (the reference keeps them state-major with a 500-frame cap, TF:107-114).
+ *   - one ghmm_ctx per GPU per host thread; no global mutable state.
+ *   - the library needs a gfx950 device: ghmm_ctx_create fails with
+ *     GHMM_ERR_NODEVICE otherwise.  There is no CPU fallback.
+ */
+#ifndef GHMM_H
+#define GHMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GHMM_VERSION 100
+
+enum {
+    GHMM_OK = 0,
+    GHMM_ERR_ARG = 1,         /* bad argument / shape mismatch */
+    GHMM_ERR_ALLOC = 2,       /* host or device allocation failed */
+    GHMM_ERR_HIP = 3,         /* a HIP runtime call failed */
+    GHMM_ERR_NODEVICE = 4,    /* no usable gfx950 device */
+    GHMM_ERR_UNSUPPORTED = 5, /* valid request outside what is built (e.g. P > 1) */
+    GHMM_ERR_IO = 6,          /* file could not be opened / read / written */
+    GHMM_ERR_FORMAT = 7       /* file content is not a .perfil / .hmm */
+};
+
+const char *ghmm_strerror(int code);
+const char *ghmm_last_error(void); /* thread-local detail of the last failure */
+int ghmm_version(void);
+
+/* ------------------------------------------------------------------ context */
+
+typedef struct ghmm_ctx ghmm_ctx;
+
+/* `hip_stream` may be NULL (the library creates its own stream) or a
+ * hipStream_t owned by the caller (e.g. torch's current stream); every kernel
+ * and copy of this context is issued on it. */
+int ghmm_ctx_create(int device, void *hip_stream, ghmm_ctx **out);
+void ghmm_ctx_destroy(ghmm_ctx *ctx);
+int ghmm_ctx_sync(ghmm_ctx *ctx);
+
+enum {
+    /* band of transitions that receive statistics: i <= j <= i+delta.
+     * The reference hard-codes DELTA 1 (TF:38, TF:1601). Default 1. */
+    GHMM_OPT_DELTA = 1,
+    /* 0 (default): emission densities in the reference's linear domain
+     *    (exp() underflows exactly where the reference's does, TF:1821-1836);
+     * 1: per-frame max-normalised densities (finite where the reference is not;
+     *    the log of the normaliser is added back into the log-likelihood). */
+    GHMM_OPT_ROBUST = 2,
+    /* 0 auto, 1 vector-ALU kernels, 2 MFMA (f64 16x16x4) kernels */
+    GHMM_OPT_KERNELS = 3,
+    /* 1: bracket every kernel with HIP events on the context's stream */
+    GHMM_OPT_TIMING = 4,
+    /* number of frame-block partial sums kept by the statistics kernel (0 auto) */
+    GHMM_OPT_PARTIALS = 5
+};
+int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value);
+int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value);
+
+/* kernel ids for ghmm_ctx_kernel_time() */
+enum {
+    GHMM_K_EMISSION = 0,
+    GHMM_K_FORWARD = 1,
+    GHMM_K_BACKWARD = 2,
+    GHMM_K_MIXSTATS = 3,
+    GHMM_K_REDUCE = 4,
+    GHMM_K_MSTEP = 5,
+    GHMM_K_VITERBI = 6,
+    GHMM_K_PREPARE = 7,
+    GHMM_K_COUNT = 8
+};
+/* Sum of HIP-event durations and launch count since the last reset (needs
+ * GHMM_OPT_TIMING = 1).  Synchronises the context's stream. */
+int ghmm_ctx_kernel_time(ghmm_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
+int ghmm_ctx_kernel_time_reset(ghmm_ctx *ctx);
+const char *ghmm_kernel_name(int kernel);
+
+/* -------------------------------------------------------------------- model */
+
+typedef struct ghmm_model ghmm_model;
+
+/* Device-resident model, one feature stream (the reference's param_number P;
+ * every BASELINE configuration uses P = 1). Replaces `struct state
+ * state_mix[P][N]` + `transition_probab[N][N]` (TF:104, TF:146). */
+int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model **out);
+void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m);
+/* host -> device; also rebuilds the derived per-Gaussian constants
+ * (pow(2*pi, D/2) * sqrt(|det|), TF:1821-1827). */
+int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, const double *c,
+                   const double *mean, const double *inv_var, const double *det);
+/* device -> host (synchronises); any pointer may be NULL */
+int ghmm_model_get(ghmm_ctx *ctx, ghmm_model *m, double *A, double *c, double *mean,
+                   double *inv_var, double *det);
+int ghmm_model_dims(const ghmm_model *m, int *N, int *M, int *D);
+
+/* ------------------------------------------------------------------- corpus */
+
+typedef struct ghmm_corpus ghmm_corpus;
+
+/* A batch of utterances resident in HBM.  `len[u]` = frames of utterance u.
+ * _create copies host frames to the device; _wrap adopts a device pointer the
+ * caller keeps alive (no copy). Replaces the per-frame fread loop TF:282-288. */
+int ghmm_corpus_create(ghmm_ctx *ctx, const double *X_host, const int32_t *len, int n_utt, int D,
+                       ghmm_corpus **out);
+int ghmm_corpus_wrap(ghmm_ctx *ctx, const double *X_dev, const int32_t *len, int n_utt, int D,
+                     ghmm_corpus **out);
+void ghmm_corpus_destroy(ghmm_ctx *ctx, ghmm_corpus *c);
+int64_t ghmm_corpus_frames(const ghmm_corpus *c);
+int ghmm_corpus_utterances(const ghmm_corpus *c);
+
+/* ---------------------------------------------------- sufficient statistics */
+
+/* Flat Baum-Welch accumulator vector — the ONLY thing that crosses GPUs
+ * (one all-reduce(SUM) per EM iteration).  Layout, in doubles:
+ *   num_a[N*N]   TF:1614  (only the band i <= j <= i+delta is ever non-zero)
+ *   den_a[N]     TF:1618
+ *   den_c[N]     TF:1660
+ *   num_c[N*M]   TF:1716
+ *   num_mu[N*M*D]  TF:1718
+ *   num_var[N*M*D] TF:1720-1722 (around the OLD mean)
+ *   loglik       TF:318  (sum of per-utterance log P)
+ *   n_utt        TF:320
+ */
+typedef struct ghmm_stats ghmm_stats;
+size_t ghmm_stats_len(int N, int M, int D);
+int ghmm_stats_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_stats **out);
+/* adopt caller-owned device memory of ghmm_stats_len() doubles (e.g. a torch
+ * tensor that torch.distributed all-reduces in place) */
+int ghmm_stats_wrap(ghmm_ctx *ctx, int N, int M, int D, double *dev_ptr, ghmm_stats **out);
+void ghmm_stats_destroy(ghmm_ctx *ctx, ghmm_stats *s);
+double *ghmm_stats_device_ptr(ghmm_stats *s);
+int ghmm_stats_download(ghmm_ctx *ctx, ghmm_stats *s, double *host);
+int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *host);
+
+/* ---------------------------------------------- the path, one row at a time */
+
+/* calc_symbol_probab + calc_gaus, TF:1749-1841 (want_post = 1: also the
+ * within-state mixture posteriors `gauss[i][j]`, TF:1773-1778) and RF:860-947
+ * (want_post = 0).  Results stay in the context workspace. */
+int ghmm_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int want_post);
+/* calc_alpha TF:1380-1443 / RF:739-799 + calc_probability TF:1536-1553 */
+int ghmm_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c);
+/* calc_beta TF:1463-1516, fused with the per-utterance part of
+ * calc_transition_probab TF:1577-1620 and calc_den_mix_coef TF:1642-1664 */
+int ghmm_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c);
+/* calc_mix_param TF:1691-1727 over every frame, then the ordered reduction of
+ * all partial sums into `stats` */
+int ghmm_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *stats);
+
+/* workspace buffers readable with ghmm_fetch (all double, frame-major) */
+enum {
+    GHMM_BUF_B = 0,      /* b[F][N]        symbol_probab        TF:107 */
+    GHMM_BUF_POST = 1,   /* post[F][N*M]   gaus_probab_dens     TF:110 */
+    GHMM_BUF_ALPHA = 2,  /* alpha^[F][N]                        TF:112 */
+    GHMM_BUF_BETA = 3,   /* beta^[F][N]                         TF:114 */
+    GHMM_BUF_SCALE = 4,  /* c_t[F]         scaling_factor       TF:116 */
+    GHMM_BUF_GAMMA = 5,  /* gamma[F][N] = alpha^*beta^/c_t      TF:1657 */
+    GHMM_BUF_LOGLIK = 6, /* log P per utterance [U]             TF:1536 */
+    GHMM_BUF_LOGNORM = 7 /* log of the per-frame normaliser [F] (GHMM_OPT_ROBUST) */
+};
+int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n_doubles);
+
+/* -------------------------------------------------- the path, batched/fused */
+
+/* One E-step over the whole corpus: emission -> forward -> backward ->
+ * statistics -> ordered reduction (TF:244-321).  `stats` is overwritten (the
+ * zeroing of TF:244-270 is implied).  Asynchronous on the context's stream. */
+int ghmm_estep(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *stats);
+/* M-step from (possibly all-reduced) statistics, on the device, in place:
+ * updating_transition_probab TF:1862-1889, updating_mix_param TF:1911-1955 with
+ * changing_zero_coef TF:1338-1359, calc_det TF:1976 + inv_matrix TF:2012 as
+ * called at TF:343-346.  Asynchronous. */
+int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *stats);
+/* Forward-algorithm score per utterance (RF:354-366): emission without
+ * posteriors + alpha + log P.  Synchronises, writes loglik[U] on the host. */
+int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *loglik_host);
+/* Max-plus lattice with the reference's one-hot start (RF:249-251) and
+ * final-state termination (TF:1487, TF:1549); ties take the lowest predecessor.
+ * ABSENT from the reference: defined by oracle/.
+ * path_host[F] = state per frame, score_host[U] = best log score. */
+int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_t *path_host,
+                 double *score_host);
+
+/* ------------------------------------------------- host side: file formats */
+
+#define GHMM_MAX_WORD 256
+
+/* .perfil: int32 D, then T*D doubles, T implied by EOF (TF:527-581).
+ * *X is malloc'ed; the caller frees it with ghmm_free(). */
+int ghmm_perfil_read(const char *path, int *D, int *T, double **X);
+int ghmm_perfil_write(const char *path, int D, int T, const double *X);
+void ghmm_free(void *p);
+
+/* .hmm model file (writer TF:2043-2146, readers TF:604-711, RF:595-715), one
+ * stream.  The reader accepts both a 4-byte and an 8-byte length prefix (the
+ * shipped models come from a 32-bit build); the writer emits `len_bytes`
+ * (8 = what a 64-bit build of the reference writes, or 4). Arrays are malloc'ed
+ * by the reader. */
+typedef struct ghmm_host_model {
+    char word[GHMM_MAX_WORD];
+    int N, M, D;
+    double *A, *c, *mean, *inv_var, *det;
+} ghmm_host_model;
+int ghmm_host_model_alloc(ghmm_host_model *hm, int N, int M, int D);
+void ghmm_host_model_free(ghmm_host_model *hm);
+int ghmm_hmm_read(const char *path, ghmm_host_model *hm);
+int ghmm_hmm_write(const char *path, const ghmm_host_model *hm, int len_bytes);
+
+/* creating_initial_model TF:732-1317 (uniform segmentation, LBG splitting with
+ * factors 1.005/0.995, three k-means passes, per-cell variance floored at 1e-5)
+ * on utterances already in host memory.  Host code. */
+int ghmm_init_model(const double *X, const int32_t *len, int n_utt, int N, int M, int D,
+                    ghmm_host_model *hm);
+
+/* -------------------------------------------- host side: synthetic corpora */
+
+#define GHMM_SYNTH_SEED 20260104ull
+
+/* ground truth: mean[N*M*D] ~ N(0, 2^2), stddev[N*M*D] ~ U[0.5, 1.5] */
+int ghmm_synth_truth(uint64_t seed, int N, int M, int D, double *mean, double *stddev);
+/* utterances first_utt .. first_utt+n_utt-1 of the corpus (seed): left-to-right
+ * walk over the N states, one mixture per frame.  X holds sum(len)*D doubles. */
+int ghmm_synth_utterances(uint64_t seed, int N, int M, int D, const double *mean,
+                          const double *stddev, int64_t first_utt, int n_utt,
+                          const int32_t *len, double *X);
+/* starting model = truth perturbed by +-perturb (relative on stddev, in units
+ * of stddev on the mean), uniform mixture weights, one-step left-to-right A */
+int ghmm_synth_start_model(uint64_t seed, int N, int M, int D, const double *mean,
+                           const double *stddev, double perturb, double *A, double *c,
+                           double *mu0, double *inv_var0, double *det0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GHMM_H */

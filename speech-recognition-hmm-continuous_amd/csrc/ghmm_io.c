@@ -1,0 +1,237 @@
+/*
+ * ghmm_io.c — host side of the drop-in boundary: the reference's on-disk formats
+ * (SURVEY.md §2.1).  Plain C, no device code.
+ *
+ *   .perfil  int32 D, then T*D little-endian doubles; T implied by EOF
+ *            (reader TF:527-581: one fread of D doubles per frame)
+ *   .hmm     size_t len | word[len] | int N | int P | int M[P] | int D[P] |
+ *            double A[N][N] | per stream, per state: double c[M], then per
+ *            mixture: double mean[D], double det, double inv_var[D]
+ *            (writer TF:2043-2146, readers TF:604-711 / RF:595-715)
+ *
+ * The shipped .hmm files were written by a 32-bit build (4-byte size_t), a
+ * 64-bit build writes 8 bytes: the reader accepts both by checking which header
+ * width makes the file length come out exactly.
+ */
+#include "ghmm.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static _Thread_local char g_err[512];
+
+void ghmm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+const char *ghmm_last_error(void) { return g_err; }
+
+const char *ghmm_strerror(int code)
+{
+    switch (code) {
+    case GHMM_OK: return "ok";
+    case GHMM_ERR_ARG: return "bad argument";
+    case GHMM_ERR_ALLOC: return "allocation failed";
+    case GHMM_ERR_HIP: return "HIP runtime error";
+    case GHMM_ERR_NODEVICE: return "no gfx950 device";
+    case GHMM_ERR_UNSUPPORTED: return "unsupported configuration";
+    case GHMM_ERR_IO: return "file i/o error";
+    case GHMM_ERR_FORMAT: return "bad file format";
+    default: return "unknown error";
+    }
+}
+
+int ghmm_version(void) { return GHMM_VERSION; }
+
+void ghmm_free(void *p) { free(p); }
+
+static long file_size(FILE *f)
+{
+    long cur = ftell(f), end;
+    if (fseek(f, 0, SEEK_END) != 0) return -1;
+    end = ftell(f);
+    fseek(f, cur, SEEK_SET);
+    return end;
+}
+
+int ghmm_perfil_read(const char *path, int *D, int *T, double **X)
+{
+    if (!path || !D || !T || !X) return GHMM_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        ghmm_set_error("file %s not found", path);
+        return GHMM_ERR_IO;
+    }
+    int32_t d = 0;
+    long size = file_size(f);
+    if (size < 4 || fread(&d, sizeof d, 1, f) != 1 || d <= 0 || d > (1 << 20)) {
+        fclose(f);
+        ghmm_set_error("%s: not a .perfil file", path);
+        return GHMM_ERR_FORMAT;
+    }
+    /* whole frames only; the reference would also consume a ragged tail
+       (TF:537 returns the item count), which no writer produces */
+    long frames = (size - 4) / (long)(sizeof(double) * (size_t)d);
+    double *buf = (double *)malloc(sizeof(double) * (size_t)(frames > 0 ? frames : 1) * (size_t)d);
+    if (!buf) {
+        fclose(f);
+        return GHMM_ERR_ALLOC;
+    }
+    size_t want = (size_t)frames * (size_t)d;
+    if (fread(buf, sizeof(double), want, f) != want) {
+        fclose(f);
+        free(buf);
+        ghmm_set_error("reading error on file %s", path);
+        return GHMM_ERR_IO;
+    }
+    fclose(f);
+    *D = d;
+    *T = (int)frames;
+    *X = buf;
+    return GHMM_OK;
+}
+
+int ghmm_perfil_write(const char *path, int D, int T, const double *X)
+{
+    if (!path || D <= 0 || T < 0 || (!X && T > 0)) return GHMM_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        ghmm_set_error("can't open file %s", path);
+        return GHMM_ERR_IO;
+    }
+    int32_t d = D;
+    size_t n = (size_t)T * (size_t)D;
+    int ok = fwrite(&d, sizeof d, 1, f) == 1 && fwrite(X, sizeof(double), n, f) == n;
+    if (fclose(f) != 0) ok = 0;
+    if (!ok) {
+        ghmm_set_error("writing error on file %s", path);
+        return GHMM_ERR_IO;
+    }
+    return GHMM_OK;
+}
+
+int ghmm_host_model_alloc(ghmm_host_model *hm, int N, int M, int D)
+{
+    if (!hm || N <= 0 || M <= 0 || D <= 0) return GHMM_ERR_ARG;
+    size_t G = (size_t)N * M;
+    hm->N = N; hm->M = M; hm->D = D;
+    hm->A = (double *)calloc((size_t)N * N, sizeof(double));
+    hm->c = (double *)calloc(G, sizeof(double));
+    hm->mean = (double *)calloc(G * D, sizeof(double));
+    hm->inv_var = (double *)calloc(G * D, sizeof(double));
+    hm->det = (double *)calloc(G, sizeof(double));
+    if (!hm->A || !hm->c || !hm->mean || !hm->inv_var || !hm->det) {
+        ghmm_host_model_free(hm);
+        return GHMM_ERR_ALLOC;
+    }
+    return GHMM_OK;
+}
+
+void ghmm_host_model_free(ghmm_host_model *hm)
+{
+    if (!hm) return;
+    free(hm->A); free(hm->c); free(hm->mean); free(hm->inv_var); free(hm->det);
+    hm->A = hm->c = hm->mean = hm->inv_var = hm->det = NULL;
+}
+
+/* try to parse with a `lb`-byte length prefix; 0 = fits the file exactly */
+static int hmm_try(FILE *f, long size, int lb, ghmm_host_model *hm, const char *path)
+{
+    unsigned char raw[8] = {0};
+    rewind(f);
+    if (fread(raw, 1, (size_t)lb, f) != (size_t)lb) return GHMM_ERR_FORMAT;
+    uint64_t len = 0;
+    for (int i = lb - 1; i >= 0; i--) len = (len << 8) | raw[i];
+    if (len >= GHMM_MAX_WORD) return GHMM_ERR_FORMAT;
+    char word[GHMM_MAX_WORD] = {0};
+    int32_t N = 0, P = 0, M = 0, D = 0;
+    if (fread(word, 1, (size_t)len, f) != (size_t)len) return GHMM_ERR_FORMAT;
+    if (fread(&N, 4, 1, f) != 1 || fread(&P, 4, 1, f) != 1) return GHMM_ERR_FORMAT;
+    if (N <= 0 || N > 65536 || P <= 0 || P > 64) return GHMM_ERR_FORMAT;
+    if (P != 1) {
+        /* make sure it is a plausible multi-stream file before saying so */
+        ghmm_set_error("%s: %d feature streams; only param_number = 1 is built", path, P);
+        return GHMM_ERR_UNSUPPORTED;
+    }
+    if (fread(&M, 4, 1, f) != 1 || fread(&D, 4, 1, f) != 1) return GHMM_ERR_FORMAT;
+    if (M <= 0 || M > 65536 || D <= 0 || D > 65536) return GHMM_ERR_FORMAT;
+    long expect = lb + (long)len + 16 +
+                  8L * ((long)N * N + (long)N * ((long)M + (long)M * (2L * D + 1)));
+    if (expect != size) return GHMM_ERR_FORMAT;
+    int rc = ghmm_host_model_alloc(hm, N, M, D);
+    if (rc) return rc;
+    memcpy(hm->word, word, GHMM_MAX_WORD);
+    int ok = fread(hm->A, 8, (size_t)N * N, f) == (size_t)N * N;
+    for (int i = 0; ok && i < N; i++) {
+        ok = fread(hm->c + (size_t)i * M, 8, (size_t)M, f) == (size_t)M;
+        for (int k = 0; ok && k < M; k++) {
+            size_t g = (size_t)i * M + k;
+            ok = fread(hm->mean + g * D, 8, (size_t)D, f) == (size_t)D &&
+                 fread(hm->det + g, 8, 1, f) == 1 &&
+                 fread(hm->inv_var + g * D, 8, (size_t)D, f) == (size_t)D;
+        }
+    }
+    if (!ok) {
+        ghmm_host_model_free(hm);
+        return GHMM_ERR_IO;
+    }
+    return GHMM_OK;
+}
+
+int ghmm_hmm_read(const char *path, ghmm_host_model *hm)
+{
+    if (!path || !hm) return GHMM_ERR_ARG;
+    memset(hm, 0, sizeof *hm);
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        ghmm_set_error("file %s not found", path);
+        return GHMM_ERR_IO;
+    }
+    long size = file_size(f);
+    int rc = hmm_try(f, size, 8, hm, path);
+    if (rc == GHMM_ERR_FORMAT) rc = hmm_try(f, size, 4, hm, path);
+    fclose(f);
+    if (rc == GHMM_ERR_FORMAT)
+        ghmm_set_error("%s: not a diagonal-covariance .hmm file (4- or 8-byte header)", path);
+    else if (rc == GHMM_ERR_IO)
+        ghmm_set_error("reading error on file %s", path);
+    return rc;
+}
+
+int ghmm_hmm_write(const char *path, const ghmm_host_model *hm, int len_bytes)
+{
+    if (!path || !hm || (len_bytes != 4 && len_bytes != 8)) return GHMM_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        ghmm_set_error("can't open file %s", path);
+        return GHMM_ERR_IO;
+    }
+    int N = hm->N, M = hm->M, D = hm->D;
+    int32_t hdr[4] = {N, 1, M, D};
+    uint64_t len = strnlen(hm->word, GHMM_MAX_WORD - 1);
+    int ok = fwrite(&len, 1, (size_t)len_bytes, f) == (size_t)len_bytes; /* little-endian */
+    ok = ok && fwrite(hm->word, 1, (size_t)len, f) == (size_t)len;
+    ok = ok && fwrite(hdr, 4, 4, f) == 4;
+    ok = ok && fwrite(hm->A, 8, (size_t)N * N, f) == (size_t)N * N;
+    for (int i = 0; ok && i < N; i++) {
+        ok = fwrite(hm->c + (size_t)i * M, 8, (size_t)M, f) == (size_t)M;
+        for (int k = 0; ok && k < M; k++) {
+            size_t g = (size_t)i * M + k;
+            ok = fwrite(hm->mean + g * D, 8, (size_t)D, f) == (size_t)D &&
+                 fwrite(hm->det + g, 8, 1, f) == 1 &&
+                 fwrite(hm->inv_var + g * D, 8, (size_t)D, f) == (size_t)D;
+        }
+    }
+    if (fclose(f) != 0) ok = 0;
+    if (!ok) {
+        ghmm_set_error("writing error on file %s", path);
+        return GHMM_ERR_IO;
+    }
+    return GHMM_OK;
+}

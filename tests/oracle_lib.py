@@ -1,0 +1,133 @@
+"""ctypes face of oracle/libghmm_oracle.so (TEST INFRASTRUCTURE: the CPU
+restatement of the reference path).  Imported by tests/, smoke() and bench.py's
+cpu_baseline leg only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "libghmm_oracle.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"),
+                                   os.path.join(ROOT, "oracle", "libghmm_oracle.so")])
+        L = C.CDLL(LIB)
+        L.orc_stats_len.restype = C.c_size_t
+        L.orc_stats_len.argtypes = [C.c_int] * 3
+        L.orc_estep.restype = C.c_int
+        L.orc_estep.argtypes = [C.c_int] * 4 + [_dp] * 6 + [_ip, C.c_int] + [_dp] * 7
+        L.orc_mstep.restype = None
+        L.orc_mstep.argtypes = [C.c_int] * 3 + [_dp] * 6
+        L.orc_train.restype = C.c_int
+        L.orc_train.argtypes = ([C.c_int] * 4 + [C.c_double, C.c_int, C.c_int] + [_dp] * 6 +
+                                [_ip, C.c_int, _dp, _dp])
+        L.orc_score.restype = C.c_double
+        L.orc_score.argtypes = [C.c_int] * 4 + [_dp] * 6
+        L.orc_viterbi.restype = C.c_double
+        L.orc_viterbi.argtypes = [C.c_int] * 4 + [_dp] * 6 + [_ip]
+        L.orc_viterbi_lattice.restype = C.c_double
+        L.orc_viterbi_lattice.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip]
+        L.orc_log_emission.restype = None
+        L.orc_log_emission.argtypes = [C.c_int] * 4 + [_dp] * 6
+        L.orc_sort_scores.restype = None
+        L.orc_sort_scores.argtypes = [C.c_int, _dp, _ip]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _marr(hm):
+    return [_d(x) for x in (hm.A, hm.c, hm.mean, hm.inv_var, hm.det)]
+
+
+def stats_len(N, M, D):
+    return lib().orc_stats_len(N, M, D)
+
+
+def estep(hm, X, lens, delta=1, dumps=True):
+    """One E-step (TF:244-321).  Returns (stats, dict of per-frame arrays)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    N, M, D = hm.N, hm.M, hm.D
+    F, U = int(lens.sum()), len(lens)
+    stats = np.zeros(stats_len(N, M, D))
+    out = {}
+    if dumps:
+        out = dict(b=np.zeros((F, N)), post=np.zeros((F, N, M)), alpha=np.zeros((F, N)),
+                   beta=np.zeros((F, N)), scale=np.zeros(F), loglik=np.zeros(U))
+    rc = lib().orc_estep(N, M, D, delta, *_marr(hm), _d(X), lens.ctypes.data_as(_ip), U,
+                         _d(stats), _d(out.get("b")), _d(out.get("post")), _d(out.get("alpha")),
+                         _d(out.get("beta")), _d(out.get("scale")), _d(out.get("loglik")))
+    assert rc == 0
+    return stats, out
+
+
+def mstep(hm, stats):
+    """In-place M-step (TF:332-346) on a copy of hm; returns the new model."""
+    new = hm.copy()
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    lib().orc_mstep(hm.N, hm.M, hm.D, _d(stats), *_marr(new))
+    return new
+
+
+def train(hm, X, lens, delta=1, threshold=1e-3, max_iter=0, fixed_iter=False):
+    """EM driver (TF:238-358).  Returns (model, iterations, mean loglik, trace)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    new = hm.copy()
+    mean_ll = C.c_double()
+    trace = np.zeros(max(max_iter, 1) if max_iter > 0 else 1000)
+    it = lib().orc_train(hm.N, hm.M, hm.D, delta, threshold, max_iter, int(fixed_iter),
+                         *_marr(new), _d(X), lens.ctypes.data_as(_ip), len(lens),
+                         C.byref(mean_ll), _d(trace))
+    assert it > 0
+    return new, it, mean_ll.value, trace[:it].copy()
+
+
+def score(hm, X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    return lib().orc_score(hm.N, hm.M, hm.D, X.shape[0], *_marr(hm), _d(X))
+
+
+def viterbi(hm, X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    path = np.zeros(X.shape[0], dtype=np.int32)
+    s = lib().orc_viterbi(hm.N, hm.M, hm.D, X.shape[0], *_marr(hm), _d(X),
+                          path.ctypes.data_as(_ip))
+    return path, s
+
+
+def log_emission(hm, X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    out = np.zeros((X.shape[0], hm.N))
+    lib().orc_log_emission(hm.N, hm.M, hm.D, X.shape[0], _d(X), _d(hm.c), _d(hm.mean),
+                           _d(hm.inv_var), _d(hm.det), _d(out))
+    return out
+
+
+def viterbi_lattice(A, logb):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    logb = np.ascontiguousarray(logb, dtype=np.float64)
+    T, N = logb.shape
+    path = np.zeros(T, dtype=np.int32)
+    s = lib().orc_viterbi_lattice(N, T, _d(A), _d(logb), path.ctypes.data_as(_ip))
+    return path, s
+
+
+def sort_scores(scores):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    idx = np.zeros(len(scores), dtype=np.int32)
+    lib().orc_sort_scores(len(scores), _d(scores), idx.ctypes.data_as(_ip))
+    return idx
