@@ -1,0 +1,912 @@
+// ghmm_hip.hip — the C ABI of include/ghmm.h on top of the gfx950 kernels.
+//
+// Host logic only: contexts, device buffers, launch geometry, HIP-event timing.
+// All arithmetic of the path happens in the kernels (ghmm_kernels.hpp,
+// ghmm_mfma.hpp).  No CPU fallback: without a gfx950 device every entry point that
+// needs one fails with GHMM_ERR_NODEVICE.
+#include "ghmm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ghmm_kernels.hpp"
+
+extern "C" void ghmm_set_error(const char *fmt, ...); // ghmm_io.c
+
+using namespace ghmm;
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ghmm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                     \
+            return GHMM_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define ARG_CHECK(cond, msg)                                                              \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            ghmm_set_error("%s: %s", __func__, msg);                                      \
+            return GHMM_ERR_ARG;                                                          \
+        }                                                                                 \
+    } while (0)
+
+struct ktimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct ghmm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cus = 256;
+    int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0;
+    // workspace (grown on demand, never shrunk)
+    size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
+           cap_lognorm = 0, cap_loglik = 0, cap_pxi = 0, cap_pdena = 0, cap_pdenc = 0, cap_pmu = 0,
+           cap_pvar = 0, cap_psi = 0, cap_path = 0;
+    double *b = nullptr, *post = nullptr, *alpha = nullptr, *beta = nullptr, *gamma = nullptr;
+    double *scale = nullptr, *lognorm = nullptr, *loglik = nullptr;
+    double *part_xi = nullptr, *part_dena = nullptr, *part_denc = nullptr;
+    double *part_mu = nullptr, *part_var = nullptr;
+    unsigned char *psi = nullptr;
+    int *path = nullptr;
+    // shape of what the workspace currently holds (for ghmm_fetch)
+    long long F = 0;
+    int U = 0, N = 0, G = 0;
+    bool b_is_log = false;
+    ktimer kt[GHMM_K_COUNT];
+};
+
+struct ghmm_model {
+    int N = 0, M = 0, D = 0;
+    double *A = nullptr, *c = nullptr, *mean = nullptr, *inv_var = nullptr, *det = nullptr;
+    double *wk = nullptr, *logwk = nullptr, *logA = nullptr;
+};
+
+struct ghmm_corpus {
+    const double *X = nullptr;
+    bool own = false;
+    long long *off = nullptr; // device, U+1
+    std::vector<int32_t> len;
+    long long F = 0;
+    int U = 0, D = 0, Tmax = 0;
+};
+
+struct ghmm_stats {
+    int N = 0, M = 0, D = 0;
+    double *v = nullptr;
+    bool own = false;
+    size_t n = 0;
+};
+
+static const char *k_names[GHMM_K_COUNT] = {"emission", "forward", "backward", "mixstats",
+                                            "reduce",   "mstep",   "viterbi",  "prepare"};
+
+extern "C" const char *ghmm_kernel_name(int k)
+{
+    return (k >= 0 && k < GHMM_K_COUNT) ? k_names[k] : "?";
+}
+
+// ----------------------------------------------------------------- helpers
+
+template <class T> static int dev_grow(T **p, size_t *cap, size_t need)
+{
+    if (need <= *cap && *p) return GHMM_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t n = need ? need : 1;
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+    *cap = n;
+    return GHMM_OK;
+}
+
+template <class T> static int dev_alloc(T **p, size_t n)
+{
+    HIP_TRY(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+    return GHMM_OK;
+}
+
+struct kscope { // brackets one kernel launch with HIP events when timing is on
+    ghmm_ctx *ctx;
+    int k;
+    hipEvent_t a = nullptr, b = nullptr;
+    kscope(ghmm_ctx *c, int kid) : ctx(c), k(kid)
+    {
+        if (!ctx->timing) return;
+        ktimer &t = ctx->kt[k];
+        if (!t.pool.empty()) {
+            a = t.pool.back().first;
+            b = t.pool.back().second;
+            t.pool.pop_back();
+        } else {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+                a = b = nullptr;
+                return;
+            }
+        }
+        (void)hipEventRecord(a, ctx->stream);
+    }
+    ~kscope()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->kt[k].pending.push_back({a, b});
+    }
+};
+
+static int launch_ok(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ghmm_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return GHMM_ERR_HIP;
+    }
+    return GHMM_OK;
+}
+
+static int use(ghmm_ctx *ctx)
+{
+    if (!ctx) {
+        ghmm_set_error("null context");
+        return GHMM_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    return GHMM_OK;
+}
+
+// ----------------------------------------------------------------- context
+
+extern "C" int ghmm_ctx_create(int device, void *hip_stream, ghmm_ctx **out)
+{
+    ARG_CHECK(out, "null output");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        ghmm_set_error("no HIP device visible; the GMM-HMM path has no CPU fallback");
+        return GHMM_ERR_NODEVICE;
+    }
+    ARG_CHECK(device >= 0 && device < n, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ghmm_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                       prop.gcnArchName);
+        return GHMM_ERR_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    ghmm_ctx *ctx = new (std::nothrow) ghmm_ctx();
+    if (!ctx) return GHMM_ERR_ALLOC;
+    ctx->device = device;
+    ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            ghmm_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return GHMM_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return GHMM_OK;
+}
+
+extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    void *bufs[] = {ctx->b,       ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
+                    ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
+                    ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    for (auto &t : ctx->kt) {
+        for (auto &e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto &e : t.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int ghmm_ctx_sync(ghmm_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value)
+{
+    ARG_CHECK(ctx, "null context");
+    switch (option) {
+    case GHMM_OPT_DELTA:
+        ARG_CHECK(value >= 0 && value <= MAX_DELTA, "delta out of range (0..7)");
+        ctx->delta = value;
+        break;
+    case GHMM_OPT_ROBUST:
+        ARG_CHECK(value == 0 || value == 1, "robust must be 0 or 1");
+        ctx->robust = value;
+        break;
+    case GHMM_OPT_KERNELS:
+        ARG_CHECK(value >= 0 && value <= 2, "kernels must be 0, 1 or 2");
+        ctx->kernels = value;
+        break;
+    case GHMM_OPT_TIMING:
+        ctx->timing = value ? 1 : 0;
+        break;
+    case GHMM_OPT_PARTIALS:
+        ARG_CHECK(value >= 0 && value <= 65535, "partials out of range");
+        ctx->partials = value;
+        break;
+    default:
+        ghmm_set_error("unknown option %d", option);
+        return GHMM_ERR_ARG;
+    }
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value)
+{
+    ARG_CHECK(ctx && value, "null argument");
+    switch (option) {
+    case GHMM_OPT_DELTA: *value = ctx->delta; break;
+    case GHMM_OPT_ROBUST: *value = ctx->robust; break;
+    case GHMM_OPT_KERNELS: *value = ctx->kernels; break;
+    case GHMM_OPT_TIMING: *value = ctx->timing; break;
+    case GHMM_OPT_PARTIALS: *value = ctx->partials; break;
+    default:
+        ghmm_set_error("unknown option %d", option);
+        return GHMM_ERR_ARG;
+    }
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_ctx_kernel_time(ghmm_ctx *ctx, int kernel, double *total_ms, int64_t *launches)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(kernel >= 0 && kernel < GHMM_K_COUNT, "kernel id out of range");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ktimer &t = ctx->kt[kernel];
+    for (auto &e : t.pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        t.ms += ms;
+        t.launches++;
+        t.pool.push_back(e);
+    }
+    t.pending.clear();
+    if (total_ms) *total_ms = t.ms;
+    if (launches) *launches = t.launches;
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_ctx_kernel_time_reset(ghmm_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto &t : ctx->kt) {
+        for (auto &e : t.pending) t.pool.push_back(e);
+        t.pending.clear();
+        t.ms = 0.0;
+        t.launches = 0;
+    }
+    return GHMM_OK;
+}
+
+// ------------------------------------------------------------------- model
+
+static int model_prepare(ghmm_ctx *ctx, ghmm_model *m)
+{
+    // pow(2*pi, D/2): the reference's aux1 (TF:1821-1823), evaluated by the host libm
+    const double norm2pi = pow(2.0 * M_PI, m->D / 2.0);
+    const int G = m->N * m->M;
+    int work = G > m->N * m->N ? G : m->N * m->N;
+    int blocks = (work + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    {
+        kscope ks(ctx, GHMM_K_PREPARE);
+        hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(256), 0, ctx->stream, m->N, m->M, m->A,
+                           m->c, m->det, norm2pi, m->wk, m->logwk, m->logA);
+    }
+    return launch_ok("k_prepare");
+}
+
+extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model **out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(out && N > 0 && M > 0 && D > 0, "bad dimensions");
+    ARG_CHECK((long long)N * M < (1ll << 30), "too many Gaussians");
+    ghmm_model *m = new (std::nothrow) ghmm_model();
+    if (!m) return GHMM_ERR_ALLOC;
+    m->N = N; m->M = M; m->D = D;
+    size_t G = (size_t)N * M;
+    if ((rc = dev_alloc(&m->A, (size_t)N * N)) || (rc = dev_alloc(&m->c, G)) ||
+        (rc = dev_alloc(&m->mean, G * D)) || (rc = dev_alloc(&m->inv_var, G * D)) ||
+        (rc = dev_alloc(&m->det, G)) || (rc = dev_alloc(&m->wk, G)) ||
+        (rc = dev_alloc(&m->logwk, G)) || (rc = dev_alloc(&m->logA, (size_t)N * N))) {
+        ghmm_model_destroy(ctx, m);
+        return rc;
+    }
+    *out = m;
+    return GHMM_OK;
+}
+
+extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
+{
+    if (!m) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    void *bufs[] = {m->A, m->c, m->mean, m->inv_var, m->det, m->wk, m->logwk, m->logA};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, const double *c,
+                              const double *mean, const double *inv_var, const double *det)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(m && A && c && mean && inv_var && det, "null argument");
+    size_t G = (size_t)m->N * m->M, NN = (size_t)m->N * m->N;
+    HIP_TRY(hipMemcpyAsync(m->A, A, NN * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(m->c, c, G * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(m->mean, mean, G * m->D * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(m->inv_var, inv_var, G * m->D * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(m->det, det, G * 8, hipMemcpyHostToDevice, ctx->stream));
+    // pageable host memory: the copies above have consumed the buffers on return
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return model_prepare(ctx, m);
+}
+
+extern "C" int ghmm_model_get(ghmm_ctx *ctx, ghmm_model *m, double *A, double *c, double *mean,
+                              double *inv_var, double *det)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(m, "null model");
+    size_t G = (size_t)m->N * m->M, NN = (size_t)m->N * m->N;
+    if (A) HIP_TRY(hipMemcpyAsync(A, m->A, NN * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (c) HIP_TRY(hipMemcpyAsync(c, m->c, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (mean) HIP_TRY(hipMemcpyAsync(mean, m->mean, G * m->D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (inv_var)
+        HIP_TRY(hipMemcpyAsync(inv_var, m->inv_var, G * m->D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (det) HIP_TRY(hipMemcpyAsync(det, m->det, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_model_dims(const ghmm_model *m, int *N, int *M, int *D)
+{
+    ARG_CHECK(m, "null model");
+    if (N) *N = m->N;
+    if (M) *M = m->M;
+    if (D) *D = m->D;
+    return GHMM_OK;
+}
+
+// ------------------------------------------------------------------ corpus
+
+static int corpus_make(ghmm_ctx *ctx, const double *X_host, const double *X_dev, const int32_t *len,
+                       int n_utt, int D, ghmm_corpus **out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(out && len && n_utt >= 0 && D > 0, "bad arguments");
+    ghmm_corpus *c = new (std::nothrow) ghmm_corpus();
+    if (!c) return GHMM_ERR_ALLOC;
+    c->U = n_utt;
+    c->D = D;
+    c->len.assign(len, len + n_utt);
+    std::vector<long long> off((size_t)n_utt + 1, 0);
+    for (int u = 0; u < n_utt; u++) {
+        if (len[u] < 0) {
+            delete c;
+            ghmm_set_error("negative utterance length");
+            return GHMM_ERR_ARG;
+        }
+        off[u + 1] = off[u] + len[u];
+        if (len[u] > c->Tmax) c->Tmax = len[u];
+    }
+    c->F = off[n_utt];
+    if ((rc = dev_alloc(&c->off, off.size()))) {
+        delete c;
+        return rc;
+    }
+    hipError_t e = hipMemcpy(c->off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice);
+    if (e == hipSuccess && X_host) {
+        double *xd = nullptr;
+        if ((rc = dev_alloc(&xd, (size_t)c->F * D))) {
+            (void)hipFree(c->off);
+            delete c;
+            return rc;
+        }
+        c->X = xd;
+        c->own = true;
+        if (c->F) e = hipMemcpy(xd, X_host, (size_t)c->F * D * 8, hipMemcpyHostToDevice);
+    } else {
+        c->X = X_dev;
+    }
+    if (e != hipSuccess) {
+        ghmm_set_error("corpus upload failed: %s", hipGetErrorString(e));
+        if (c->own) (void)hipFree((void *)c->X);
+        (void)hipFree(c->off);
+        delete c;
+        return GHMM_ERR_HIP;
+    }
+    *out = c;
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_corpus_create(ghmm_ctx *ctx, const double *X_host, const int32_t *len, int n_utt,
+                                  int D, ghmm_corpus **out)
+{
+    ARG_CHECK(X_host || n_utt == 0, "null frames");
+    static const double dummy = 0.0;
+    return corpus_make(ctx, X_host ? X_host : &dummy, nullptr, len, n_utt, D, out);
+}
+
+extern "C" int ghmm_corpus_wrap(ghmm_ctx *ctx, const double *X_dev, const int32_t *len, int n_utt,
+                                int D, ghmm_corpus **out)
+{
+    ARG_CHECK(X_dev, "null device pointer");
+    return corpus_make(ctx, nullptr, X_dev, len, n_utt, D, out);
+}
+
+extern "C" void ghmm_corpus_destroy(ghmm_ctx *ctx, ghmm_corpus *c)
+{
+    if (!c) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (c->own && c->X) (void)hipFree((void *)c->X);
+    if (c->off) (void)hipFree(c->off);
+    delete c;
+}
+
+extern "C" int64_t ghmm_corpus_frames(const ghmm_corpus *c) { return c ? c->F : -1; }
+extern "C" int ghmm_corpus_utterances(const ghmm_corpus *c) { return c ? c->U : -1; }
+
+// ------------------------------------------------------------------- stats
+
+extern "C" size_t ghmm_stats_len(int N, int M, int D)
+{
+    return (size_t)N * N + 2 * (size_t)N + (size_t)N * M * (2 * (size_t)D + 1) + 2;
+}
+
+extern "C" int ghmm_stats_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_stats **out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(out && N > 0 && M > 0 && D > 0, "bad dimensions");
+    ghmm_stats *s = new (std::nothrow) ghmm_stats();
+    if (!s) return GHMM_ERR_ALLOC;
+    s->N = N; s->M = M; s->D = D;
+    s->n = ghmm_stats_len(N, M, D);
+    s->own = true;
+    if ((rc = dev_alloc(&s->v, s->n))) {
+        delete s;
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(s->v, 0, s->n * 8, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(s->v);
+        delete s;
+        ghmm_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+        return GHMM_ERR_HIP;
+    }
+    *out = s;
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_stats_wrap(ghmm_ctx *ctx, int N, int M, int D, double *dev_ptr, ghmm_stats **out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(out && dev_ptr && N > 0 && M > 0 && D > 0, "bad arguments");
+    ghmm_stats *s = new (std::nothrow) ghmm_stats();
+    if (!s) return GHMM_ERR_ALLOC;
+    s->N = N; s->M = M; s->D = D;
+    s->n = ghmm_stats_len(N, M, D);
+    s->v = dev_ptr;
+    s->own = false;
+    *out = s;
+    return GHMM_OK;
+}
+
+extern "C" void ghmm_stats_destroy(ghmm_ctx *ctx, ghmm_stats *s)
+{
+    if (!s) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (s->own && s->v) (void)hipFree(s->v);
+    delete s;
+}
+
+extern "C" double *ghmm_stats_device_ptr(ghmm_stats *s) { return s ? s->v : nullptr; }
+
+extern "C" int ghmm_stats_download(ghmm_ctx *ctx, ghmm_stats *s, double *host)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(s && host, "null argument");
+    HIP_TRY(hipMemcpyAsync(host, s->v, s->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *host)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(s && host, "null argument");
+    HIP_TRY(hipMemcpyAsync(s->v, host, s->n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+// --------------------------------------------------------------- workspace
+
+static int check_pair(const ghmm_model *m, const ghmm_corpus *c)
+{
+    if (!m || !c) {
+        ghmm_set_error("null model or corpus");
+        return GHMM_ERR_ARG;
+    }
+    if (m->D != c->D) {
+        ghmm_set_error("model has %d coefficients per frame, corpus has %d", m->D, c->D);
+        return GHMM_ERR_ARG;
+    }
+    return GHMM_OK;
+}
+
+static int ws_frames(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c, bool want_post)
+{
+    int rc;
+    size_t F = (size_t)c->F, N = (size_t)m->N, G = (size_t)m->N * m->M;
+    if ((rc = dev_grow(&ctx->b, &ctx->cap_b, F * N))) return rc;
+    if (want_post && (rc = dev_grow(&ctx->post, &ctx->cap_post, F * G))) return rc;
+    if ((rc = dev_grow(&ctx->scale, &ctx->cap_scale, F))) return rc;
+    if ((rc = dev_grow(&ctx->lognorm, &ctx->cap_lognorm, F))) return rc;
+    if ((rc = dev_grow(&ctx->loglik, &ctx->cap_loglik, (size_t)c->U))) return rc;
+    ctx->F = c->F;
+    ctx->U = c->U;
+    ctx->N = m->N;
+    ctx->G = (int)G;
+    return GHMM_OK;
+}
+
+static int ws_fb(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
+{
+    int rc;
+    size_t FN = (size_t)c->F * m->N, UN = (size_t)c->U * m->N;
+    if ((rc = dev_grow(&ctx->alpha, &ctx->cap_alpha, FN))) return rc;
+    if ((rc = dev_grow(&ctx->beta, &ctx->cap_beta, FN))) return rc;
+    if ((rc = dev_grow(&ctx->gamma, &ctx->cap_gamma, FN))) return rc;
+    if ((rc = dev_grow(&ctx->part_xi, &ctx->cap_pxi, UN * (MAX_DELTA + 1)))) return rc;
+    if ((rc = dev_grow(&ctx->part_dena, &ctx->cap_pdena, UN))) return rc;
+    if ((rc = dev_grow(&ctx->part_denc, &ctx->cap_pdenc, UN))) return rc;
+    return GHMM_OK;
+}
+
+// --------------------------------------------------------------- emission
+
+static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, bool want_post)
+{
+    if (c->F == 0) return GHMM_OK;
+    const long long blocks = (c->F + WAVE - 1) / WAVE;
+    const size_t lds = (size_t)WAVE * (m->D | 1) * sizeof(double);
+    if (lds > 160 * 1024) {
+        ghmm_set_error("coefficient count %d too large for the emission tile", m->D);
+        return GHMM_ERR_UNSUPPORTED;
+    }
+    double *post = want_post ? ctx->post : nullptr;
+    {
+        kscope ks(ctx, GHMM_K_EMISSION);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_emission<0>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
+                               m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
+                               ctx->b, post, ctx->lognorm);
+        else if (mode == 1)
+            hipLaunchKernelGGL(k_emission<1>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
+                               m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
+                               ctx->b, post, ctx->lognorm);
+        else
+            hipLaunchKernelGGL(k_emission<2>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
+                               m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
+                               ctx->b, post, ctx->lognorm);
+    }
+    ctx->b_is_log = (mode == 2);
+    return launch_ok("k_emission");
+}
+
+extern "C" int ghmm_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int want_post)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c))) return rc;
+    if ((rc = ws_frames(ctx, m, c, want_post != 0))) return rc;
+    return run_emission(ctx, m, c, ctx->robust ? 1 : 0, want_post != 0);
+}
+
+// ------------------------------------------------------- forward / backward
+
+static int fb_lanes(const ghmm_model *m, int *L)
+{
+    if (m->N <= 16) *L = 16;
+    else if (m->N <= 64) *L = 64;
+    else {
+        ghmm_set_error("%d states: the forward-backward kernels hold one state per lane (<= 64)",
+                       m->N);
+        return GHMM_ERR_UNSUPPORTED;
+    }
+    return GHMM_OK;
+}
+
+static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+{
+    if (c->U == 0) return GHMM_OK;
+    int L, rc;
+    if ((rc = fb_lanes(m, &L))) return rc;
+    const int gpw = WAVE / L;
+    const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
+    const double *ln = ctx->robust ? ctx->lognorm : nullptr;
+    {
+        kscope ks(ctx, GHMM_K_FORWARD);
+        if (L == 16)
+            hipLaunchKernelGGL(k_forward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ln, ctx->loglik);
+        else
+            hipLaunchKernelGGL(k_forward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ln, ctx->loglik);
+    }
+    return launch_ok("k_forward");
+}
+
+static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+{
+    if (c->U == 0) return GHMM_OK;
+    int L, rc;
+    if ((rc = fb_lanes(m, &L))) return rc;
+    const int gpw = WAVE / L;
+    const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
+    {
+        kscope ks(ctx, GHMM_K_BACKWARD);
+        if (L == 16)
+            hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
+                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc);
+        else
+            hipLaunchKernelGGL(k_backward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
+                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc);
+    }
+    return launch_ok("k_backward");
+}
+
+static int need_emission(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
+{
+    if (!ctx->b || ctx->F != c->F || ctx->U != c->U || ctx->N != m->N || ctx->b_is_log) {
+        ghmm_set_error("call ghmm_emission on this model and corpus first");
+        return GHMM_ERR_ARG;
+    }
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c)) || (rc = need_emission(ctx, m, c))) return rc;
+    if ((rc = ws_fb(ctx, m, c))) return rc;
+    return run_forward(ctx, m, c);
+}
+
+extern "C" int ghmm_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c)) || (rc = need_emission(ctx, m, c))) return rc;
+    if ((rc = ws_fb(ctx, m, c))) return rc;
+    return run_backward(ctx, m, c);
+}
+
+// -------------------------------------------------------------- statistics
+
+static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *s)
+{
+    const int N = m->N, M = m->M, D = m->D, G = N * M, D1 = D + 1;
+    const long long E = (long long)G * D1;
+    const int NB = (int)((E + MS_THREADS * MS_EPT - 1) / (MS_THREADS * MS_EPT));
+    // frame-block partials: enough blocks to fill the chip a few times over, few
+    // enough that the partial sums stay small next to the frame data
+    long long P = ctx->partials > 0 ? ctx->partials : (2LL * ctx->cus + NB - 1) / NB;
+    if (P < 1) P = 1;
+    long long fpb = (c->F + P - 1) / P;
+    fpb = ((fpb + MS_FS - 1) / MS_FS) * MS_FS;
+    if (fpb < MS_FS) fpb = MS_FS;
+    P = c->F > 0 ? (c->F + fpb - 1) / fpb : 0;
+    int rc;
+    if (P > 0) {
+        size_t need = (size_t)P * (size_t)E;
+        if ((rc = dev_grow(&ctx->part_mu, &ctx->cap_pmu, need))) return rc;
+        if ((rc = dev_grow(&ctx->part_var, &ctx->cap_pvar, need))) return rc;
+        const int GWmax = (MS_THREADS * MS_EPT) / D1 + 2;
+        const size_t lds = ((size_t)MS_FS * D1 + (size_t)MS_FS * GWmax) * sizeof(double);
+        if (lds > 64 * 1024) {
+            ghmm_set_error("coefficient count %d too large for the statistics tile", D);
+            return GHMM_ERR_UNSUPPORTED;
+        }
+        {
+            kscope ks(ctx, GHMM_K_MIXSTATS);
+            hipLaunchKernelGGL(k_mixstats, dim3((unsigned)P, (unsigned)NB), dim3(MS_THREADS), lds,
+                               ctx->stream, N, M, D, c->F, fpb, c->X, ctx->gamma, ctx->post, m->mean,
+                               ctx->part_mu, ctx->part_var);
+        }
+        if ((rc = launch_ok("k_mixstats"))) return rc;
+    }
+    double *num_c = s->v + (size_t)N * N + 2 * (size_t)N;
+    double *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
+    const size_t off_ll = s->n - 2;
+    {
+        kscope ks(ctx, GHMM_K_REDUCE);
+        hipLaunchKernelGGL(k_reduce_utt, dim3((unsigned)(N * N + 2 * N + 1)), dim3(RD_THREADS), 0,
+                           ctx->stream, N, c->U, (int)ctx->delta, ctx->part_xi, ctx->part_dena,
+                           ctx->part_denc, ctx->loglik, s->v, off_ll);
+        hipLaunchKernelGGL(k_reduce_mix, dim3((unsigned)((E + RD_THREADS - 1) / RD_THREADS)),
+                           dim3(RD_THREADS), 0, ctx->stream, N, M, D, (int)P, ctx->part_mu,
+                           ctx->part_var, num_c, num_mu, num_var);
+    }
+    return launch_ok("k_reduce");
+}
+
+static int check_stats(const ghmm_model *m, const ghmm_stats *s)
+{
+    if (!s || s->N != m->N || s->M != m->M || s->D != m->D) {
+        ghmm_set_error("statistics vector does not match the model's shape");
+        return GHMM_ERR_ARG;
+    }
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *s)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c)) || (rc = need_emission(ctx, m, c)) || (rc = check_stats(m, s)))
+        return rc;
+    if (!ctx->gamma || !ctx->post) {
+        ghmm_set_error("call ghmm_emission(want_post=1), ghmm_forward and ghmm_backward first");
+        return GHMM_ERR_ARG;
+    }
+    return run_accumulate(ctx, m, c, s);
+}
+
+extern "C" int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(host, "null destination");
+    const double *src = nullptr;
+    size_t have = 0;
+    size_t F = (size_t)ctx->F, N = (size_t)ctx->N, G = (size_t)ctx->G, U = (size_t)ctx->U;
+    switch (which) {
+    case GHMM_BUF_B: src = ctx->b; have = F * N; break;
+    case GHMM_BUF_POST: src = ctx->post; have = F * G; break;
+    case GHMM_BUF_ALPHA: src = ctx->alpha; have = F * N; break;
+    case GHMM_BUF_BETA: src = ctx->beta; have = F * N; break;
+    case GHMM_BUF_SCALE: src = ctx->scale; have = F; break;
+    case GHMM_BUF_GAMMA: src = ctx->gamma; have = F * N; break;
+    case GHMM_BUF_LOGLIK: src = ctx->loglik; have = U; break;
+    case GHMM_BUF_LOGNORM: src = ctx->lognorm; have = F; break;
+    default:
+        ghmm_set_error("unknown buffer %d", which);
+        return GHMM_ERR_ARG;
+    }
+    if (!src || n != have) {
+        ghmm_set_error("buffer %d holds %zu doubles, %zu requested", which, src ? have : 0, n);
+        return GHMM_ERR_ARG;
+    }
+    if (n) HIP_TRY(hipMemcpyAsync(host, src, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+// -------------------------------------------------------------------- fused
+
+extern "C" int ghmm_estep(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *s)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c)) || (rc = check_stats(m, s))) return rc;
+    if ((rc = ws_frames(ctx, m, c, true)) || (rc = ws_fb(ctx, m, c))) return rc;
+    if ((rc = run_emission(ctx, m, c, ctx->robust ? 1 : 0, true))) return rc;
+    if ((rc = run_forward(ctx, m, c))) return rc;
+    if ((rc = run_backward(ctx, m, c))) return rc;
+    return run_accumulate(ctx, m, c, s);
+}
+
+extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(m, "null model");
+    if ((rc = check_stats(m, s))) return rc;
+    {
+        kscope ks(ctx, GHMM_K_MSTEP);
+        hipLaunchKernelGGL(k_mstep, dim3(1), dim3(256), 0, ctx->stream, m->N, m->M, m->D, s->v, m->A,
+                           m->c, m->mean, m->inv_var, m->det);
+    }
+    if ((rc = launch_ok("k_mstep"))) return rc;
+    return model_prepare(ctx, m);
+}
+
+extern "C" int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *loglik_host)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c))) return rc;
+    ARG_CHECK(loglik_host || c->U == 0, "null destination");
+    if ((rc = ws_frames(ctx, m, c, false)) || (rc = ws_fb(ctx, m, c))) return rc;
+    if ((rc = run_emission(ctx, m, c, ctx->robust ? 1 : 0, false))) return rc;
+    if ((rc = run_forward(ctx, m, c))) return rc;
+    if (c->U)
+        HIP_TRY(hipMemcpyAsync(loglik_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_t *path_host,
+                            double *score_host)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c))) return rc;
+    ARG_CHECK((path_host && score_host) || c->U == 0, "null destination");
+    int L;
+    if ((rc = fb_lanes(m, &L))) return rc;
+    ARG_CHECK(m->N <= 255, "too many states for byte back-pointers");
+    if ((rc = ws_frames(ctx, m, c, false))) return rc;
+    if ((rc = dev_grow(&ctx->psi, &ctx->cap_psi, (size_t)c->F * m->N))) return rc;
+    if ((rc = dev_grow(&ctx->path, &ctx->cap_path, (size_t)c->F))) return rc;
+    if ((rc = run_emission(ctx, m, c, 2, false))) return rc;
+    if (c->U) {
+        const int gpw = WAVE / L;
+        const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
+        {
+            kscope ks(ctx, GHMM_K_VITERBI);
+            if (L == 16)
+                hipLaunchKernelGGL(k_viterbi<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
+                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik);
+            else
+                hipLaunchKernelGGL(k_viterbi<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
+                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik);
+        }
+        if ((rc = launch_ok("k_viterbi"))) return rc;
+        HIP_TRY(hipMemcpyAsync(score_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        if (c->F)
+            HIP_TRY(hipMemcpyAsync(path_host, ctx->path, (size_t)c->F * sizeof(int),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}

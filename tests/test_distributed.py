@@ -1,0 +1,93 @@
+"""The N > 1 path on CPU: two gloo ranks, utterances sharded by rank, one all-reduce
+of the flat statistics vector per EM iteration, redundant M-step — driven by the
+same EMDriver bench.py uses, with the oracle standing in for the HIP backend (tests
+may call the oracle; the product never does)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from _load import load_pkg
+
+
+class OracleBackend:
+    def __init__(self, hm, X, lens):
+        self.hm, self.X, self.lens = hm, X, lens
+        self.t = torch.zeros(O.stats_len(hm.N, hm.M, hm.D), dtype=torch.float64)
+
+    def estep(self):
+        s, _ = O.estep(self.hm, self.X, self.lens, dumps=False)
+        self.t.copy_(torch.from_numpy(s))
+
+    def stats_tensor(self):
+        return self.t
+
+    def mstep(self):
+        self.hm = O.mstep(self.hm, self.t.numpy())
+
+    def loglik(self):
+        return float(self.t[-2])
+
+
+def _problem(G):
+    N, M, D = 5, 2, 7
+    mean, std = G.synth_truth(N, M, D)
+    lens = np.array([40, 55, 32, 61, 47, 38, 52], dtype=np.int32)
+    X = G.synth_utterances(mean, std, lens)
+    return G.synth_start_model(mean, std, 0.1), X, lens
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    G, em = pkg.ghmm, pkg.em
+    hm, X, lens = _problem(G)
+    lo, hi = em.shard_range(len(lens), rank, world)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    be = OracleBackend(hm, X[off[lo]:off[hi]], lens[lo:hi])
+    drv = em.EMDriver(be, dist)
+    for _ in range(3):
+        drv.step()
+    it, p = drv.train(threshold=1e-3, max_iter=50)
+    q.put((rank, [a.copy() for a in be.hm.arrays()], it, p, float(be.t[-1])))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one(G):
+    pkg = load_pkg()
+    em = pkg.em
+    assert [em.shard_range(7, r, 2) for r in range(2)] == [(0, 4), (4, 7)]
+    assert [em.shard_range(8, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 8)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, whole corpus
+    hm, X, lens = _problem(G)
+    be = OracleBackend(hm, X, lens)
+    drv = em.EMDriver(be)
+    for _ in range(3):
+        drv.step()
+    it, p = drv.train(threshold=1e-3, max_iter=50)
+    for rank, arrays, it_r, p_r, n_utt in res:
+        assert it_r == it and n_utt == len(lens)
+        assert abs(p_r - p) <= 1e-12 * abs(p)
+        for a, b in zip(arrays, be.hm.arrays()):
+            assert np.allclose(a, b, rtol=1e-11, atol=0)
+    # both ranks hold the same model bit for bit (same reduced statistics, same M-step)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)

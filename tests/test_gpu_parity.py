@@ -1,0 +1,454 @@
+"""Parity of the HIP path (through the C ABI) with the reference — GPU box only.
+
+Three kinds of check:
+  * against golden dumps of the REAL reference (tests/golden/*.npz, *.json),
+  * against the oracle (oracle/ghmm_oracle.c, itself bit-exact vs the reference) on
+    seeded synthetic inputs the goldens do not cover,
+  * size-independent properties at BASELINE's full sizes.
+
+Tolerance: north_star asks for log-likelihoods and re-estimated parameters within
+1e-5 relative.  The assertions below use RTOL = 1e-8 on every intermediate (the GPU
+differs from the reference only by FMA contraction, summation order and device
+exp/log), so a pass here is three orders of magnitude inside the bar.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN
+from _load import PKG_DIR
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8          # asserted
+NORTH_STAR_RTOL = 1e-5  # the bar
+
+
+def assert_close(got, ref, rtol=RTOL, floor=1e-13, what=""):
+    """|got-ref| <= rtol*|ref| + floor*max|ref|; non-finite entries must agree in kind."""
+    got = np.asarray(got, dtype=np.float64).ravel()
+    ref = np.asarray(ref, dtype=np.float64).ravel()
+    assert got.shape == ref.shape, what
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern differs"
+    assert np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)]), f"{what}: inf differs"
+    if fin.any():
+        scale = np.abs(ref[fin]).max()
+        err = np.abs(got[fin] - ref[fin])
+        tol = rtol * np.abs(ref[fin]) + floor * scale
+        worst = (err / np.maximum(tol, 1e-320)).max()
+        assert worst <= 1.0, f"{what}: worst error {worst:.3g} x tolerance"
+
+
+@pytest.fixture(scope="module")
+def ctx(G):
+    c = G.Context(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------ goldens
+
+def test_rows_against_reference_dumps(G, ctx, case):
+    """Every §8(a) row on its own, against what the reference's functions produced:
+    b, post (TF:1749-1841), alpha^, c_t, log P (TF:1380-1443, 1536-1553), beta^
+    (TF:1463-1516), gamma, and all accumulators (TF:1577-1727)."""
+    model, corpus = ctx.model(case.model0), ctx.corpus(case.X, case.lens)
+    F, N, M, D = corpus.frames, case.N, case.M, case.D
+    ctx.emission(model, corpus, True)
+    assert_close(ctx.fetch(G.BUF_B, (F, N)), case.frames("b"), what="b")
+    assert_close(ctx.fetch(G.BUF_POST, (F, N * M)), case.frames("post"), what="post")
+    ctx.forward(model, corpus)
+    assert_close(ctx.fetch(G.BUF_ALPHA, (F, N)), case.frames("alpha"), what="alpha")
+    assert_close(ctx.fetch(G.BUF_SCALE, (F,)), case.frames("scale"), what="scale")
+    assert_close(ctx.fetch(G.BUF_LOGLIK, (case.U,)), case.logliks(), what="loglik")
+    ctx.backward(model, corpus)
+    beta, scale = case.frames("beta"), case.frames("scale")
+    assert_close(ctx.fetch(G.BUF_BETA, (F, N)), beta, what="beta")
+    gamma_ref = case.frames("alpha") * beta / scale[:, None]
+    assert_close(ctx.fetch(G.BUF_GAMMA, (F, N)), gamma_ref, what="gamma")
+    stats = ctx.stats(N, M, D)
+    ctx.accumulate(model, corpus, stats)
+    got, ref = G.split_stats(stats.download(), N, M, D), G.split_stats(case.stats(), N, M, D)
+    for k in ref:
+        assert_close(got[k], ref[k], what="stats." + k)
+    for o in (model, corpus, stats):
+        o.close()
+
+
+def test_fused_estep_and_mstep_against_reference_dumps(G, ctx, case):
+    model, corpus = ctx.model(case.model0), ctx.corpus(case.X, case.lens)
+    stats = ctx.stats(case.N, case.M, case.D)
+    ctx.estep(model, corpus, stats)
+    got = G.split_stats(stats.download(), case.N, case.M, case.D)
+    ref = G.split_stats(case.stats(), case.N, case.M, case.D)
+    for k in ref:
+        assert_close(got[k], ref[k], what="stats." + k)
+    # M-step from the reference's own accumulators: isolates TF:332-346
+    stats.upload(case.stats())
+    ctx.mstep(model, stats)
+    new = model.get()
+    for name, a, b in zip(("A", "c", "mean", "inv_var", "det"), new.arrays(), case.model1.arrays()):
+        assert_close(a, b, rtol=1e-12, floor=0.0, what="model1." + name)
+    for o in (model, corpus, stats):
+        o.close()
+
+
+@pytest.fixture(scope="module")
+def whole():
+    return json.load(open(os.path.join(GOLDEN, "whole_program.json")))
+
+
+def gpu_train(G, ctx, hm0, X, lens, threshold=1e-3, max_iter=200):
+    """EM driver TF:238-358 on the GPU (what train_main.c does)."""
+    em = __import__("ghmm_amd").em
+    model, corpus = ctx.model(hm0), ctx.corpus(X, lens)
+    backend = em.HipBackend(G, ctx, model, corpus)
+    it, p = em.EMDriver(backend).train(threshold, max_iter)
+    hm = model.get()
+    for o in (model, corpus, backend.stats):
+        o.close()
+    return hm, it, p / len(lens)
+
+
+def test_training_loop_matches_reference_programs(G, ctx, whole):
+    """Iteration counts and mean log-likelihoods of the real trainer executable."""
+    models = np.load(os.path.join(GOLDEN, "train13_m1_models.npz"))
+    for word, exp in whole["train13_m1"].items():
+        X = G.perfil_read(os.path.join(GOLDEN, "perfil", f"mean_{word}.perfil"))
+        hm, it, mp = gpu_train(G, ctx, G.HostModel.init_from(X, [len(X)], 6, 1), X, [len(X)])
+        assert it == exp["iterations"], word
+        assert mp == pytest.approx(exp["mean_probability"], rel=1e-9, abs=1e-6), word
+        for k, v in zip(("A", "c", "mean", "inv_var", "det"), hm.arrays()):
+            assert_close(v, models[f"{word}.{k}"], rtol=1e-7, what=f"{word}.{k}")
+    Xs = [G.perfil_read(os.path.join(GOLDEN, "perfil", fn)) for fn in whole["mean_list"]]
+    lens = [len(x) for x in Xs]
+    X = np.concatenate(Xs)
+    hm, it, mp = gpu_train(G, ctx, G.HostModel.init_from(X, lens, 6, 3), X, lens)
+    exp = whole["train_all13_m3"]
+    assert it == exp["iterations"]
+    assert mp == pytest.approx(exp["mean_probability"], rel=1e-9, abs=1e-6)
+    for k, v in zip(("A", "c", "mean", "inv_var", "det"), hm.arrays()):
+        assert_close(v, np.array(exp["model"][k]), rtol=1e-6, what="all13." + k)
+
+
+def test_training_synth39_matches_reference_program(G, ctx, whole):
+    exp = whole["train_synth39_m8"]
+    mean, std = G.synth_truth(10, 8, 39)
+    X = G.synth_utterances(mean, std, exp["lens"], first_utt=exp["first_utt"])
+    hm, it, mp = gpu_train(G, ctx, G.HostModel.init_from(X, exp["lens"], 10, 8), X, exp["lens"])
+    assert it == exp["iterations"]
+    assert mp == pytest.approx(exp["mean_probability"], rel=1e-9, abs=1e-6)
+    ref = np.load(os.path.join(GOLDEN, "train_synth39_m8_model.npz"))
+    for k, v in zip(("A", "c", "mean", "inv_var", "det"), hm.arrays()):
+        assert_close(v, ref[k], rtol=1e-6, what="synth39." + k)
+
+
+def cfmt(x):
+    if np.isnan(x):
+        return "-nan" if np.signbit(x) else "nan"
+    return f"{x:f}"
+
+
+def test_recognition_scores_match_reference_program(G, ctx, whole):
+    """RF:326-374: forward scores of 13 utterances x 13 models, the reference's printed
+    values (finite ones within 1e-9, -inf / nan in the same places) and its ranking."""
+    models = np.load(os.path.join(GOLDEN, "train13_m1_models.npz"))
+    words = whole["words"]
+    hms = [G.HostModel(*(models[f"{w}.{k}"] for k in ("A", "c", "mean", "inv_var", "det")))
+           for w in words]
+    Xs = [G.perfil_read(os.path.join(GOLDEN, "perfil", fn)) for fn in whole["mean_list"]]
+    corpus = ctx.corpus(np.concatenate(Xs), [len(x) for x in Xs])
+    scores = np.zeros((len(words), len(Xs)))
+    for k, hm in enumerate(hms):
+        m = ctx.model(hm)
+        scores[k] = ctx.score(m, corpus)
+        m.close()
+    corpus.close()
+    for u, blk in enumerate(whole["recog13_m1"]["blocks"]):
+        order = O.sort_scores(scores[:, u])
+        assert [words[i] for i in order] == [w for w, _ in blk["ranking"]], blk["spoken"]
+        for i, (w, txt) in zip(order, blk["ranking"]):
+            if "nan" in txt or "inf" in txt:
+                assert cfmt(scores[i, u]).lstrip("-") == txt.lstrip("-"), (blk["spoken"], w)
+            else:
+                assert scores[i, u] == pytest.approx(float(txt), rel=1e-9, abs=2e-6), (blk["spoken"], w)
+
+
+# ------------------------------------------------------------- command lines
+
+def _write_lists(tmp, files, name):
+    p = os.path.join(tmp, name)
+    with open(p, "w") as f:
+        f.write("\n".join(files) + "\n")
+    return p
+
+
+def test_train_command_line(G, whole, tmp_path):
+    """bin/hmm-continuous-train-fs with the reference's argv (train/test/Run Arguments.txt)."""
+    exe = os.path.join(PKG_DIR, "bin", "hmm-continuous-train-fs")
+    word = "vc_186_f_03_ap_0225"
+    lst = _write_lists(str(tmp_path), [os.path.join(GOLDEN, "perfil", f"mean_{word}.perfil")], "parameters.txt")
+    out = os.path.join(str(tmp_path), "result.mean.hmm")
+    p = subprocess.run([exe, word, "6", "1", "1", lst, out], stdout=subprocess.PIPE)
+    assert p.returncode == 0, p.stdout.decode()
+    # report name: strtok(".") semantics (TF:205-207) -> cut at the FIRST dot of the file name
+    first_dot = out.index(".", 1)
+    report = open(out[:first_dot] + ".txt").read().split("\n")
+    exp = whole["train13_m1"][word]
+    assert report[0].startswith("Continuous HMM created using forward backward algorithm (diagonal")
+    assert report[2] == f"word: {word} " and report[3] == "number of states: 6 "
+    assert report[9] == f"mean probability: {exp['mean_probability']:f} "
+    assert report[10] == f"number of iterations: {exp['iterations']} "
+    hm = G.HostModel.read(out)
+    models = np.load(os.path.join(GOLDEN, "train13_m1_models.npz"))
+    assert hm.word == word
+    for k, v in zip(("A", "c", "mean", "inv_var", "det"), hm.arrays()):
+        assert_close(v, models[f"{word}.{k}"], rtol=1e-7, what=k)
+    # fewer than 7 arguments: usage text and exit status 1 (TF:179-191)
+    p = subprocess.run([exe, "w", "6", "1"], stdout=subprocess.PIPE)
+    assert p.returncode == 1 and p.stdout.startswith(b"Usage: hmm_continuous_fs")
+
+
+def test_recognition_command_line(G, whole, tmp_path):
+    """bin/recognition-continuous-test-fs with the reference's argv: the report must be
+    the reference's report line for line (dates and CPU times aside)."""
+    exe = os.path.join(PKG_DIR, "bin", "recognition-continuous-test-fs")
+    tmp = str(tmp_path)
+    models = np.load(os.path.join(GOLDEN, "train13_m1_models.npz"))
+    paths = []
+    for w in whole["words"]:
+        hm = G.HostModel(*(models[f"{w}.{k}"] for k in ("A", "c", "mean", "inv_var", "det")), word=w)
+        paths.append(os.path.join(tmp, w + ".hmm"))
+        hm.write(paths[-1], 8)
+    ml = _write_lists(tmp, paths, "models.txt")
+    fl = _write_lists(tmp, [os.path.join(GOLDEN, "perfil", fn) for fn in whole["mean_list"]], "mean_list.txt")
+    wl = _write_lists(tmp, whole["words"], "words.txt")
+    out = os.path.join(tmp, "hmm-result.txt")
+    p = subprocess.run([exe, "1", ml, "1", fl, wl, out], stdout=subprocess.PIPE)
+    assert p.returncode == 0, p.stdout.decode()
+    got = [l for l in open(out).read().split("\n")
+           if not l.startswith("Date and time") and "recognition time" not in l
+           and not l.startswith("Model name")]
+    assert got == whole["recog13_m1"]["report"]
+
+
+# ------------------------------------------------------------ oracle, seeded
+
+def synth_case(G, N, M, D, lens, perturb=0.05, first=0, dense_A=False, seed=3):
+    mean, std = G.synth_truth(N, M, D)
+    X = G.synth_utterances(mean, std, lens, first_utt=first)
+    hm = G.synth_start_model(mean, std, perturb)
+    if dense_A:
+        rng = np.random.default_rng(seed)
+        A = rng.random((N, N)) + 0.05
+        hm.A[:] = A / A.sum(1, keepdims=True)
+    return hm, X, np.asarray(lens, dtype=np.int32)
+
+
+@pytest.mark.parametrize("N,M,D,lens,dense", [
+    (10, 8, 39, [300, 211, 128, 77, 64, 5, 1, 2, 33, 500], False),   # ragged, T < N, T = 1
+    (10, 8, 39, [90, 120, 65], True),                                # dense A: general recursion
+    (3, 2, 5, [40, 17, 64, 65, 63, 1], False),                       # tiny model, tile edges
+    (16, 4, 13, [70, 80], True),                                     # N = group width
+    (20, 2, 9, [60, 45, 81], True),                                  # N > 16: one wave per utterance
+    (6, 3, 40, [64, 128], False),                                    # even D (LDS row padding)
+])
+def test_estep_against_oracle(G, ctx, N, M, D, lens, dense):
+    hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense)
+    ref_stats, ref = O.estep(hm, X, lens)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(N, M, D)
+    ctx.estep(model, corpus, stats)
+    F = corpus.frames
+    assert_close(ctx.fetch(G.BUF_B, (F, N)), ref["b"], what="b")
+    assert_close(ctx.fetch(G.BUF_POST, (F, N * M)), ref["post"], what="post")
+    assert_close(ctx.fetch(G.BUF_ALPHA, (F, N)), ref["alpha"], what="alpha")
+    assert_close(ctx.fetch(G.BUF_BETA, (F, N)), ref["beta"], what="beta")
+    assert_close(ctx.fetch(G.BUF_SCALE, (F,)), ref["scale"], what="scale")
+    assert_close(ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ref["loglik"], what="loglik")
+    got, refs = G.split_stats(stats.download(), N, M, D), G.split_stats(ref_stats, N, M, D)
+    for k in refs:
+        assert_close(got[k], refs[k], what="stats." + k)
+    ctx.mstep(model, stats)
+    new, ref_new = model.get(), O.mstep(hm, ref_stats)
+    for name, a, b in zip(("A", "c", "mean", "inv_var", "det"), new.arrays(), ref_new.arrays()):
+        assert_close(a, b, rtol=1e-7, what="mstep." + name)
+    for o in (model, corpus, stats):
+        o.close()
+
+
+def test_ten_em_iterations_track_the_oracle(G, ctx):
+    """Fixed iteration count (the benchmark mode): the per-iteration log-likelihood and
+    the final model stay within 1e-7 of the oracle over 10 E+M steps."""
+    hm, X, lens = synth_case(G, 10, 8, 39, [120] * 24, perturb=0.15)
+    ref_hm, it, _, trace = O.train(hm, X, lens, max_iter=10, fixed_iter=True)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    got = []
+    for _ in range(10):
+        ctx.estep(model, corpus, stats)
+        got.append(stats.download()[-2])
+        ctx.mstep(model, stats)
+    assert_close(got, trace, rtol=1e-9, what="loglik trace")
+    assert all(b >= a for a, b in zip(got, got[1:])), "EM must not decrease the likelihood"
+    for name, a, b in zip(("A", "c", "mean", "inv_var", "det"), model.get().arrays(), ref_hm.arrays()):
+        assert_close(a, b, rtol=1e-6, what="model." + name)
+    for o in (model, corpus, stats):
+        o.close()
+
+
+def test_delta_option_widens_the_transition_band(G, ctx):
+    hm, X, lens = synth_case(G, 6, 2, 7, [50, 60], dense_A=True)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(6, 2, 7)
+    for delta in (0, 1, 3):
+        ctx.set_option(G.OPT_DELTA, delta)
+        ctx.estep(model, corpus, stats)
+        ref, _ = O.estep(hm, X, lens, delta=delta, dumps=False)
+        assert_close(stats.download(), ref, what=f"delta={delta}")
+    ctx.set_option(G.OPT_DELTA, 1)
+    for o in (model, corpus, stats):
+        o.close()
+
+
+def test_viterbi_paths_identical_to_oracle(G, ctx):
+    """State sequences bit-identical, scores within 1e-10 (index work: exact)."""
+    for N, M, D, lens, dense in [(10, 8, 39, [300, 150, 64, 10, 1], False),
+                                 (5, 3, 12, [40, 80, 33], True), (20, 2, 9, [70], True)]:
+        hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense)
+        model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+        path, score = ctx.viterbi(model, corpus)
+        o = 0
+        for u, T in enumerate(lens):
+            p, s = O.viterbi(hm, X[o:o + T])
+            assert np.array_equal(path[o:o + T], p), (N, u)
+            if np.isfinite(s):
+                assert score[u] == pytest.approx(s, rel=1e-10)
+            else:
+                assert score[u] == s
+            o += T
+        model.close()
+        corpus.close()
+
+
+def test_score_equals_training_loglik_and_oracle(G, ctx):
+    hm, X, lens = synth_case(G, 10, 8, 39, [200, 100, 50])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    s = ctx.score(model, corpus)
+    o = 0
+    for u, T in enumerate(lens):
+        assert s[u] == pytest.approx(O.score(hm, X[o:o + T]), rel=1e-10)
+        o += T
+    model.close()
+    corpus.close()
+
+
+def test_robust_mode(G, ctx):
+    """GHMM_OPT_ROBUST: same statistics where the reference is finite, finite scores
+    where the reference's linear densities underflow to NaN."""
+    hm, X, lens = synth_case(G, 10, 8, 39, [100, 80])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    ref, _ = O.estep(hm, X, lens, dumps=False)
+    ctx.set_option(G.OPT_ROBUST, 1)
+    try:
+        ctx.estep(model, corpus, stats)
+        assert_close(stats.download(), ref, what="robust stats")
+        far = X * 40.0  # a hopeless mismatch: every density underflows
+        c2 = ctx.corpus(far, lens)
+        assert np.isnan(O.score(hm, far[:100]))
+        assert np.all(np.isfinite(ctx.score(model, c2)))
+        ctx.set_option(G.OPT_ROBUST, 0)
+        assert np.all(np.isnan(ctx.score(model, c2)))
+        c2.close()
+    finally:
+        ctx.set_option(G.OPT_ROBUST, 0)
+    for o in (model, corpus, stats):
+        o.close()
+
+
+def test_empty_and_degenerate_inputs(G, ctx):
+    hm, X, lens = synth_case(G, 4, 2, 6, [30, 0, 12])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(4, 2, 6)
+    ctx.estep(model, corpus, stats)
+    ref, _ = O.estep(hm, X, lens, dumps=False)   # a zero-length utterance adds nothing
+    assert_close(stats.download(), ref, what="zero-length utterance")
+    empty = ctx.corpus(np.zeros((0, 6)), np.zeros(0, dtype=np.int32))
+    ctx.estep(model, empty, stats)
+    assert np.all(stats.download() == 0.0)
+    assert ctx.score(model, empty).shape == (0,)
+    with pytest.raises(G.GhmmError):   # dimension mismatch is an error, not a crash
+        ctx.estep(model, ctx.corpus(np.zeros((4, 5)), [4]), stats)
+    with pytest.raises(G.GhmmError):
+        ctx.fetch(G.BUF_B, (7,))
+    for o in (model, corpus, stats, empty):
+        o.close()
+
+
+# ------------------------------------------------- full BASELINE sizes: properties
+
+def test_baseline_config2_properties(G, ctx):
+    """39-d, 10x8, 1 000 utterances x 300 frames (BASELINE configs[1]): identities that
+    hold at any size — posteriors sum to one, occupancies sum to the frame count, the
+    statistics are additive over utterance shards (what the all-reduce relies on),
+    and a 1 000-frame sample agrees with the oracle."""
+    N, M, D, U, T = 10, 8, 39, 1000, 300
+    mean, std = G.synth_truth(N, M, D)
+    lens = np.full(U, T, dtype=np.int32)
+    X = G.synth_utterances(mean, std, lens)
+    hm = G.synth_start_model(mean, std, 0.05)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(N, M, D)
+    ctx.estep(model, corpus, stats)
+    full = stats.download()
+    s = G.split_stats(full, N, M, D)
+    F = U * T
+    gamma = ctx.fetch(G.BUF_GAMMA, (F, N))
+    post = ctx.fetch(G.BUF_POST, (F, N, M))
+    assert np.allclose(gamma.sum(1), 1.0, rtol=0, atol=1e-12)
+    assert np.allclose(post.sum(2), 1.0, rtol=0, atol=1e-12)
+    assert s["den_c"].sum() == pytest.approx(F, rel=1e-12)
+    assert np.allclose(s["num_c"].sum(1), s["den_c"], rtol=1e-12)
+    assert np.allclose(s["num_a"].sum(1), s["den_a"], rtol=1e-10)
+    assert s["n_utt"] == U
+    # shard additivity
+    acc = np.zeros_like(full)
+    for lo, hi in ((0, 400), (400, 1000)):
+        c = ctx.corpus(X[lo * T:hi * T], lens[lo:hi])
+        ctx.estep(model, c, stats)
+        acc += stats.download()
+        c.close()
+    assert_close(acc, full, rtol=1e-11, what="shard additivity")
+    # oracle on the first 4 utterances
+    c = ctx.corpus(X[:4 * T], lens[:4])
+    ctx.estep(model, c, stats)
+    ref, _ = O.estep(hm, X[:4 * T], lens[:4], dumps=False)
+    assert_close(stats.download(), ref, what="sample vs oracle")
+    # the decode config (configs[2], scaled to this corpus): every path is a valid
+    # left-to-right walk from state 0 to state N-1
+    path, score = ctx.viterbi(model, corpus)
+    p = path.reshape(U, T)
+    assert np.all(p[:, 0] == 0) and np.all(p[:, -1] == N - 1)
+    step = np.diff(p, axis=1)
+    assert np.all((step == 0) | (step == 1))
+    assert np.all(score <= ctx.score(model, corpus) + 1e-9)   # best path <= all paths
+    for o in (model, corpus, stats, c):
+        o.close()
+
+
+def test_config4_shape_64_mixtures(G, ctx):
+    """10 states x 64 mixtures (BASELINE configs[3] model) on a slice the oracle can replay."""
+    hm, X, lens = synth_case(G, 10, 64, 39, [150, 90, 200, 64])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 64, 39)
+    ctx.estep(model, corpus, stats)
+    ref, _ = O.estep(hm, X, lens, dumps=False)
+    assert_close(stats.download(), ref, what="64-mixture stats")
+    for o in (model, corpus, stats):
+        o.close()
