@@ -743,25 +743,30 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     // enough that the partial sums stay small next to the frame data
     long long P = ctx->partials > 0 ? ctx->partials : (2LL * ctx->cus + NB - 1) / NB;
     if (P < 1) P = 1;
+    // frames staged through LDS per pass: x[FS][D+1] + w[FS][GW], GW = Gaussians that a
+    // batch of 256*EPT elements can touch; keep the tile under 48 KB
+    int GWmax = (MS_THREADS * MS_EPT) / D1 + 2;
+    if (GWmax > G) GWmax = G;
+    int FS = MS_FS;
+    while (FS > 1 && (size_t)FS * (D1 + GWmax) * sizeof(double) > 48 * 1024) FS /= 2;
+    const size_t lds = (size_t)FS * (D1 + GWmax) * sizeof(double);
+    if (lds > 64 * 1024) {
+        ghmm_set_error("coefficient count %d too large for the statistics tile", D);
+        return GHMM_ERR_UNSUPPORTED;
+    }
     long long fpb = (c->F + P - 1) / P;
-    fpb = ((fpb + MS_FS - 1) / MS_FS) * MS_FS;
-    if (fpb < MS_FS) fpb = MS_FS;
+    fpb = ((fpb + FS - 1) / FS) * FS;
+    if (fpb < FS) fpb = FS;
     P = c->F > 0 ? (c->F + fpb - 1) / fpb : 0;
     int rc;
     if (P > 0) {
         size_t need = (size_t)P * (size_t)E;
         if ((rc = dev_grow(&ctx->part_mu, &ctx->cap_pmu, need))) return rc;
         if ((rc = dev_grow(&ctx->part_var, &ctx->cap_pvar, need))) return rc;
-        const int GWmax = (MS_THREADS * MS_EPT) / D1 + 2;
-        const size_t lds = ((size_t)MS_FS * D1 + (size_t)MS_FS * GWmax) * sizeof(double);
-        if (lds > 64 * 1024) {
-            ghmm_set_error("coefficient count %d too large for the statistics tile", D);
-            return GHMM_ERR_UNSUPPORTED;
-        }
         {
             kscope ks(ctx, GHMM_K_MIXSTATS);
             hipLaunchKernelGGL(k_mixstats, dim3((unsigned)P, (unsigned)NB), dim3(MS_THREADS), lds,
-                               ctx->stream, N, M, D, c->F, fpb, c->X, ctx->gamma, ctx->post, m->mean,
+                               ctx->stream, N, M, D, c->F, fpb, FS, c->X, ctx->gamma, ctx->post, m->mean,
                                ctx->part_mu, ctx->part_var);
         }
         if ((rc = launch_ok("k_mixstats"))) return rc;

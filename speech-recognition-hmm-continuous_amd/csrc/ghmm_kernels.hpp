@@ -87,10 +87,10 @@ k_emission(int N, int M, int D, long long F, const double *__restrict__ X,
             b[f * N + i] = bi;
             if (pf) {
                 // gauss[i][j] /= b_i, or 0 when b_i == 0 (TF:1773-1778)
-                double r = bi != 0.0 ? 1.0 / bi : 0.0;
+                // a true division: b_i can be subnormal, where 1/b_i overflows
                 for (int j = 0; j < M; j++) {
                     double v = pf[i * M + j];
-                    pf[i * M + j] = bi != 0.0 ? v * r : 0.0;
+                    pf[i * M + j] = bi != 0.0 ? v / bi : 0.0;
                 }
             }
         }
@@ -142,8 +142,7 @@ k_emission(int N, int M, int D, long long F, const double *__restrict__ X,
                 b[f * N + i] = (mi == -INFINITY) ? -INFINITY : mi + log(s);
             }
             if (pf) {
-                double r = s != 0.0 ? 1.0 / s : 0.0;
-                for (int j = 0; j < M; j++) pf[i * M + j] = s != 0.0 ? pf[i * M + j] * r : 0.0;
+                for (int j = 0; j < M; j++) pf[i * M + j] = s != 0.0 ? pf[i * M + j] / s : 0.0;
             }
         }
     }
@@ -388,10 +387,10 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
 // partial sums; k_reduce adds them in block order (bitwise reproducible).
 constexpr int MS_THREADS = 256;
 constexpr int MS_EPT = 8;
-constexpr int MS_FS = 32;
+constexpr int MS_FS = 32; // frames staged per pass (fewer when a wide tile would not fit LDS)
 
 __global__ void __launch_bounds__(MS_THREADS)
-k_mixstats(int N, int M, int D, long long F, long long frames_per_block,
+k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
            const double *__restrict__ X, const double *__restrict__ gamma,
            const double *__restrict__ post, const double *__restrict__ mean,
            double *__restrict__ part_mu, double *__restrict__ part_var)
@@ -405,8 +404,8 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block,
     const int g0 = (int)(e0 / D1);
     const int g1 = (int)((e1 - 1) / D1); // inclusive
     const int GW = g1 - g0 + 1;
-    double *xs = lds;                     // [MS_FS][D1]
-    double *ws = lds + MS_FS * D1;        // [MS_FS][GW]
+    double *xs = lds;                // [FS][D1]
+    double *ws = lds + FS * D1;      // [FS][GW]
 
     int gx[MS_EPT], dx[MS_EPT];
     double mu[MS_EPT], acc_mu[MS_EPT], acc_var[MS_EPT];
@@ -424,8 +423,8 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block,
     }
     const long long fb0 = (long long)blockIdx.x * frames_per_block;
     const long long fb1 = (fb0 + frames_per_block < F) ? fb0 + frames_per_block : F;
-    for (long long fs = fb0; fs < fb1; fs += MS_FS) {
-        const int nf = (int)((fb1 - fs) < MS_FS ? (fb1 - fs) : MS_FS);
+    for (long long fs = fb0; fs < fb1; fs += FS) {
+        const int nf = (int)((fb1 - fs) < FS ? (fb1 - fs) : FS);
         __syncthreads();
         for (int k = tid; k < nf * D1; k += MS_THREADS) {
             int r = k / D1, d = k - r * D1;

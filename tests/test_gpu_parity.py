@@ -295,7 +295,8 @@ def test_ten_em_iterations_track_the_oracle(G, ctx):
         got.append(stats.download()[-2])
         ctx.mstep(model, stats)
     assert_close(got, trace, rtol=1e-9, what="loglik trace")
-    assert all(b >= a for a, b in zip(got, got[1:])), "EM must not decrease the likelihood"
+    # (no monotonicity check: the reference re-estimates variances around the OLD mean,
+    # TF:1720-1722, so its iteration is not exact EM and may dip)
     for name, a, b in zip(("A", "c", "mean", "inv_var", "det"), model.get().arrays(), ref_hm.arrays()):
         assert_close(a, b, rtol=1e-6, what="model." + name)
     for o in (model, corpus, stats):
@@ -306,12 +307,14 @@ def test_delta_option_widens_the_transition_band(G, ctx):
     hm, X, lens = synth_case(G, 6, 2, 7, [50, 60], dense_A=True)
     model, corpus = ctx.model(hm), ctx.corpus(X, lens)
     stats = ctx.stats(6, 2, 7)
-    for delta in (0, 1, 3):
-        ctx.set_option(G.OPT_DELTA, delta)
-        ctx.estep(model, corpus, stats)
-        ref, _ = O.estep(hm, X, lens, delta=delta, dumps=False)
-        assert_close(stats.download(), ref, what=f"delta={delta}")
-    ctx.set_option(G.OPT_DELTA, 1)
+    try:
+        for delta in (0, 1, 3):
+            ctx.set_option(G.OPT_DELTA, delta)
+            ctx.estep(model, corpus, stats)
+            ref, _ = O.estep(hm, X, lens, delta=delta, dumps=False)
+            assert_close(stats.download(), ref, what=f"delta={delta}")
+    finally:
+        ctx.set_option(G.OPT_DELTA, 1)
     for o in (model, corpus, stats):
         o.close()
 
@@ -349,8 +352,9 @@ def test_score_equals_training_loglik_and_oracle(G, ctx):
 
 
 def test_robust_mode(G, ctx):
-    """GHMM_OPT_ROBUST: same statistics where the reference is finite, finite scores
-    where the reference's linear densities underflow to NaN."""
+    """GHMM_OPT_ROBUST (per-frame max-normalised densities): same statistics where the
+    reference is finite, finite scores where whole frames underflow in the reference's
+    linear domain (its scale becomes 1/0 and the score NaN)."""
     hm, X, lens = synth_case(G, 10, 8, 39, [100, 80])
     model, corpus = ctx.model(hm), ctx.corpus(X, lens)
     stats = ctx.stats(10, 8, 39)
@@ -359,13 +363,17 @@ def test_robust_mode(G, ctx):
     try:
         ctx.estep(model, corpus, stats)
         assert_close(stats.download(), ref, what="robust stats")
-        far = X * 40.0  # a hopeless mismatch: every density underflows
-        c2 = ctx.corpus(far, lens)
-        assert np.isnan(O.score(hm, far[:100]))
-        assert np.all(np.isfinite(ctx.score(model, c2)))
+        # the same data under a model whose variances are 49x too small: every linear
+        # density is exp(-0.5 * 39 * 49) = 0, the reference's scale becomes 1/0 -> NaN
+        sharp = hm.copy()
+        sharp.inv_var *= 49.0
+        sharp.det /= 49.0 ** 39
+        m2 = ctx.model(sharp)
+        assert np.isnan(O.score(sharp, X[:100]))
+        assert np.all(np.isfinite(ctx.score(m2, corpus)))
         ctx.set_option(G.OPT_ROBUST, 0)
-        assert np.all(np.isnan(ctx.score(model, c2)))
-        c2.close()
+        assert np.all(np.isnan(ctx.score(m2, corpus)))
+        m2.close()
     finally:
         ctx.set_option(G.OPT_ROBUST, 0)
     for o in (model, corpus, stats):
