@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "ghmm_kernels.hpp"
+#include "ghmm_mfma.hpp"
 
 extern "C" void ghmm_set_error(const char *fmt, ...); // ghmm_io.c
 
@@ -72,6 +73,12 @@ struct ghmm_model {
     int N = 0, M = 0, D = 0;
     double *A = nullptr, *c = nullptr, *mean = nullptr, *inv_var = nullptr, *det = nullptr;
     double *wk = nullptr, *logwk = nullptr, *logA = nullptr;
+    // matrix-core tier (ghmm_mfma.hpp): padded geometry and B fragments
+    int Mp = 0, NT = 0, DP = 0, TC = 0, tps = 1;
+    size_t em_lds = 0;
+    bool mfma_ok = false;
+    double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *condp = nullptr;
+    int *gmap = nullptr;
 };
 
 struct ghmm_corpus {
@@ -326,7 +333,15 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m)
         hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(256), 0, ctx->stream, m->N, m->M, m->A,
                            m->c, m->det, norm2pi, m->wk, m->logwk, m->logA);
     }
-    return launch_ok("k_prepare");
+    int rc = launch_ok("k_prepare");
+    if (rc || !m->mfma_ok) return rc;
+    {
+        kscope ks(ctx, GHMM_K_PREPARE);
+        hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)((m->NT * 16 + 63) / 64)), dim3(64), 0,
+                           ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
+                           m->wk, m->Wm, m->offs, m->wkp, m->gmap, m->condp);
+    }
+    return launch_ok("k_prepare_mfma");
 }
 
 extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model **out)
@@ -346,6 +361,33 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
         ghmm_model_destroy(ctx, m);
         return rc;
     }
+    // matrix-core geometry: mixtures padded to a power of two (<= 16) or a multiple of 16
+    {
+        int Mp = 1;
+        if (M <= 16) while (Mp < M) Mp <<= 1;
+        else Mp = (M + 15) / 16 * 16;
+        m->Mp = Mp;
+        m->tps = Mp > 16 ? Mp / 16 : 1;
+        m->NT = (int)(((size_t)N * Mp + 15) / 16);
+        m->DP = (D + 1 + 3) / 4 * 4;
+        const size_t per_tile = (size_t)(m->DP / 2) * 64 * 8 + (size_t)m->DP * 8;
+        int tcmax = (int)((56 * 1024) / per_tile);
+        int TC = tcmax / m->tps * m->tps;
+        if (TC > m->NT) TC = m->NT;
+        m->TC = TC;
+        m->em_lds = (size_t)TC * per_tile + (size_t)EM_WAVES * 16 * (m->DP + 1) * 8;
+        m->mfma_ok = TC >= m->tps && TC > 0 && m->em_lds <= 150 * 1024;
+        if (m->mfma_ok) {
+            size_t nw = (size_t)m->NT * (m->DP / 2) * 64;
+            if ((rc = dev_alloc(&m->Wm, nw)) || (rc = dev_alloc(&m->offs, (size_t)m->NT * m->DP)) ||
+                (rc = dev_alloc(&m->wkp, (size_t)m->NT * 16)) ||
+                (rc = dev_alloc(&m->condp, (size_t)m->NT * 16)) ||
+                (rc = dev_alloc(&m->gmap, (size_t)m->NT * 16))) {
+                ghmm_model_destroy(ctx, m);
+                return rc;
+            }
+        }
+    }
     *out = m;
     return GHMM_OK;
 }
@@ -357,7 +399,8 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    void *bufs[] = {m->A, m->c, m->mean, m->inv_var, m->det, m->wk, m->logwk, m->logA};
+    void *bufs[] = {m->A,  m->c,    m->mean, m->inv_var, m->det,   m->wk,  m->logwk,
+                    m->logA, m->Wm, m->offs, m->wkp,     m->condp, m->gmap};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete m;
@@ -625,6 +668,29 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         return GHMM_ERR_UNSUPPORTED;
     }
     double *post = want_post ? ctx->post : nullptr;
+    if (mode == 0 && m->mfma_ok && ctx->kernels != 1) {
+        static bool lds_attr_set = false;
+        if (!lds_attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_emission_mfma,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            lds_attr_set = true;
+        }
+        const long long ntf = (c->F + 15) / 16;
+        const int chunks = (m->NT + m->TC - 1) / m->TC;
+        long long gx = (ntf + EM_WAVES - 1) / EM_WAVES;
+        long long cap = (2LL * ctx->cus + chunks - 1) / chunks;
+        if (cap < 32) cap = 32;
+        if (gx > cap) gx = cap;
+        {
+            kscope ks(ctx, GHMM_K_EMISSION);
+            hipLaunchKernelGGL(k_emission_mfma, dim3((unsigned)gx, (unsigned)chunks),
+                               dim3(EM_WAVES * WAVE), m->em_lds, ctx->stream, m->N, m->M, m->Mp, m->D,
+                               m->DP, m->NT, m->TC, c->F, c->X, m->Wm, m->offs, m->wkp, m->gmap,
+                               m->condp, m->mean, m->inv_var, ctx->b, post);
+        }
+        ctx->b_is_log = false;
+        return launch_ok("k_emission_mfma");
+    }
     {
         kscope ks(ctx, GHMM_K_EMISSION);
         if (mode == 0)
