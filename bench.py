@@ -108,7 +108,9 @@ def main():
         driver.step()
     kt = ctx.kernel_times()
     ctx.set_option(G.OPT_TIMING, 0)
-    kavg = {k: (ms / n if n else None) for k, (ms, n) in kt.items()}
+    # per EM step: total HIP-event time of each kernel class / steps (a class may hold
+    # several launches per step, e.g. "reduce")
+    kavg = {k: (ms / args.steps if n else None) for k, (ms, n) in kt.items()}
 
     if rank == 0:
         Gn = N * M

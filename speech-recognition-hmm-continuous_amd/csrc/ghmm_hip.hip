@@ -55,11 +55,11 @@ struct ghmm_ctx {
     // workspace (grown on demand, never shrunk)
     size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
            cap_lognorm = 0, cap_loglik = 0, cap_pxi = 0, cap_pdena = 0, cap_pdenc = 0, cap_pmu = 0,
-           cap_pvar = 0, cap_psi = 0, cap_path = 0;
+           cap_pvar = 0, cap_psi = 0, cap_path = 0, cap_pm = 0, cap_sums = 0;
     double *b = nullptr, *post = nullptr, *alpha = nullptr, *beta = nullptr, *gamma = nullptr;
     double *scale = nullptr, *lognorm = nullptr, *loglik = nullptr;
     double *part_xi = nullptr, *part_dena = nullptr, *part_denc = nullptr;
-    double *part_mu = nullptr, *part_var = nullptr;
+    double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr, *sums = nullptr;
     unsigned char *psi = nullptr;
     int *path = nullptr;
     // shape of what the workspace currently holds (for ghmm_fetch)
@@ -78,7 +78,9 @@ struct ghmm_model {
     size_t em_lds = 0;
     bool mfma_ok = false;
     double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *condp = nullptr;
-    int *gmap = nullptr;
+    double *oglob = nullptr, *condg = nullptr;
+    int *gmap = nullptr, *anyflag = nullptr;
+    int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
 };
 
 struct ghmm_corpus {
@@ -219,7 +221,8 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->b,       ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
-                    ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path};
+                    ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
+                    ctx->part_m,  ctx->sums};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &t : ctx->kt) {
@@ -337,9 +340,13 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m)
     if (rc || !m->mfma_ok) return rc;
     {
         kscope ks(ctx, GHMM_K_PREPARE);
+        hipLaunchKernelGGL(k_prepare_offsets, dim3((unsigned)(m->NT + m->D)), dim3(64), 0, ctx->stream,
+                           m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob);
         hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)((m->NT * 16 + 63) / 64)), dim3(64), 0,
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
-                           m->wk, m->Wm, m->offs, m->wkp, m->gmap, m->condp);
+                           m->wk, m->offs, m->oglob, m->Wm, m->wkp, m->gmap, m->condp, m->condg);
+        hipLaunchKernelGGL(k_any_flag, dim3(1), dim3(256), 0, ctx->stream, m->NT * 16, m->condg,
+                           m->anyflag);
     }
     return launch_ok("k_prepare_mfma");
 }
@@ -382,10 +389,17 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
             if ((rc = dev_alloc(&m->Wm, nw)) || (rc = dev_alloc(&m->offs, (size_t)m->NT * m->DP)) ||
                 (rc = dev_alloc(&m->wkp, (size_t)m->NT * 16)) ||
                 (rc = dev_alloc(&m->condp, (size_t)m->NT * 16)) ||
-                (rc = dev_alloc(&m->gmap, (size_t)m->NT * 16))) {
+                (rc = dev_alloc(&m->gmap, (size_t)m->NT * 16)) ||
+                (rc = dev_alloc(&m->condg, (size_t)m->NT * 16)) ||
+                (rc = dev_alloc(&m->oglob, (size_t)m->DP)) || (rc = dev_alloc(&m->anyflag, 1))) {
                 ghmm_model_destroy(ctx, m);
                 return rc;
             }
+            // statistics kernel: NE feature tiles of 16 over [x', 1, x'^2]; CT Gaussian tiles
+            // per wave so that CT*NE accumulator tiles (8 VGPRs each) stay near 200 VGPRs
+            m->NE = (2 * m->DP + 15) / 16;
+            static const int ct_of_ne[9] = {0, 8, 8, 8, 6, 5, 4, 3, 3};
+            m->CT = m->NE <= 8 ? ct_of_ne[m->NE] : 0;
         }
     }
     *out = m;
@@ -399,8 +413,8 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    void *bufs[] = {m->A,  m->c,    m->mean, m->inv_var, m->det,   m->wk,  m->logwk,
-                    m->logA, m->Wm, m->offs, m->wkp,     m->condp, m->gmap};
+    void *bufs[] = {m->A,  m->c,    m->mean, m->inv_var, m->det,   m->wk,    m->logwk, m->logA,
+                    m->Wm, m->offs, m->wkp,  m->condp,   m->gmap,  m->oglob, m->condg, m->anyflag};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete m;
@@ -800,11 +814,24 @@ extern "C" int ghmm_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
 
 // -------------------------------------------------------------- statistics
 
+template <int CT, int NE>
+static void launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int P, int chunks)
+{
+    const size_t lds = (size_t)CT * NE * 4 * 64 * sizeof(double);
+    hipLaunchKernelGGL((k_mixstats_mfma<CT, NE>), dim3((unsigned)P, (unsigned)chunks),
+                       dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT,
+                       c->F, c->X, ctx->gamma, ctx->post, m->gmap, m->oglob, ctx->part_m);
+}
+
 static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *s)
 {
     const int N = m->N, M = m->M, D = m->D, G = N * M, D1 = D + 1;
     const long long E = (long long)G * D1;
     const int NB = (int)((E + MS_THREADS * MS_EPT - 1) / (MS_THREADS * MS_EPT));
+    const bool mfma = m->mfma_ok && m->CT > 0 && ctx->kernels != 1;
+    int rc;
+    double *num_c = s->v + (size_t)N * N + 2 * (size_t)N;
+    double *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
     // frame-block partials: enough blocks to fill the chip a few times over, few
     // enough that the partial sums stay small next to the frame data
     long long P = ctx->partials > 0 ? ctx->partials : (2LL * ctx->cus + NB - 1) / NB;
@@ -824,21 +851,48 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     fpb = ((fpb + FS - 1) / FS) * FS;
     if (fpb < FS) fpb = FS;
     P = c->F > 0 ? (c->F + fpb - 1) / fpb : 0;
-    int rc;
+    const int *only_if = mfma ? m->anyflag : nullptr;
     if (P > 0) {
         size_t need = (size_t)P * (size_t)E;
         if ((rc = dev_grow(&ctx->part_mu, &ctx->cap_pmu, need))) return rc;
         if ((rc = dev_grow(&ctx->part_var, &ctx->cap_pvar, need))) return rc;
+    }
+    int Pm = 0;
+    size_t nsum = 0;
+    if (mfma) {
+        // matrix-core statistics: one partial per block, one block per CU
+        const int chunks = (m->NT + m->CT - 1) / m->CT;
+        Pm = ctx->cus;
+        const long long steps = (c->F + 3) / 4;
+        if (steps < (long long)Pm * MSM_WAVES) Pm = (int)((steps + MSM_WAVES - 1) / MSM_WAVES);
+        if (Pm < 1) Pm = 1;
+        nsum = (size_t)m->NT * 16 * m->NE * 16;
+        if ((rc = dev_grow(&ctx->part_m, &ctx->cap_pm, (size_t)Pm * nsum))) return rc;
+        if ((rc = dev_grow(&ctx->sums, &ctx->cap_sums, nsum))) return rc;
         {
             kscope ks(ctx, GHMM_K_MIXSTATS);
-            hipLaunchKernelGGL(k_mixstats, dim3((unsigned)P, (unsigned)NB), dim3(MS_THREADS), lds,
-                               ctx->stream, N, M, D, c->F, fpb, FS, c->X, ctx->gamma, ctx->post, m->mean,
-                               ctx->part_mu, ctx->part_var);
+            switch (m->NE) {
+            case 1: launch_mixstats_mfma<8, 1>(ctx, m, c, Pm, chunks); break;
+            case 2: launch_mixstats_mfma<8, 2>(ctx, m, c, Pm, chunks); break;
+            case 3: launch_mixstats_mfma<8, 3>(ctx, m, c, Pm, chunks); break;
+            case 4: launch_mixstats_mfma<6, 4>(ctx, m, c, Pm, chunks); break;
+            case 5: launch_mixstats_mfma<5, 5>(ctx, m, c, Pm, chunks); break;
+            case 6: launch_mixstats_mfma<4, 6>(ctx, m, c, Pm, chunks); break;
+            case 7: launch_mixstats_mfma<3, 7>(ctx, m, c, Pm, chunks); break;
+            default: launch_mixstats_mfma<3, 8>(ctx, m, c, Pm, chunks); break;
+            }
         }
+        if ((rc = launch_ok("k_mixstats_mfma"))) return rc;
+    }
+    if (P > 0) {
+        // vector-ALU statistics: the whole job on that tier, or (matrix-core tier) only
+        // when the model holds ill-conditioned Gaussians, whose sums it then supplies
+        kscope ks(ctx, GHMM_K_MIXSTATS);
+        hipLaunchKernelGGL(k_mixstats, dim3((unsigned)P, (unsigned)NB), dim3(MS_THREADS), lds,
+                           ctx->stream, N, M, D, c->F, fpb, FS, c->X, ctx->gamma, ctx->post, m->mean,
+                           ctx->part_mu, ctx->part_var, only_if);
         if ((rc = launch_ok("k_mixstats"))) return rc;
     }
-    double *num_c = s->v + (size_t)N * N + 2 * (size_t)N;
-    double *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
     const size_t off_ll = s->n - 2;
     {
         kscope ks(ctx, GHMM_K_REDUCE);
@@ -847,7 +901,15 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
                            ctx->part_denc, ctx->loglik, s->v, off_ll);
         hipLaunchKernelGGL(k_reduce_mix, dim3((unsigned)((E + RD_THREADS - 1) / RD_THREADS)),
                            dim3(RD_THREADS), 0, ctx->stream, N, M, D, (int)P, ctx->part_mu,
-                           ctx->part_var, num_c, num_mu, num_var);
+                           ctx->part_var, num_c, num_mu, num_var, only_if);
+        if (mfma) {
+            hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nsum + 63) / 64)), dim3(256), 0,
+                               ctx->stream, (long long)nsum, c->F > 0 ? Pm : 0, ctx->part_m, ctx->sums);
+            const long long nfin = (long long)m->NT * 16 * D1;
+            hipLaunchKernelGGL(k_finish_mix, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0,
+                               ctx->stream, N, M, D, m->DP, m->NT, m->NE * 16, ctx->sums, m->gmap,
+                               m->condg, m->oglob, m->mean, num_c, num_mu, num_var);
+        }
     }
     return launch_ok("k_reduce");
 }

@@ -393,9 +393,11 @@ __global__ void __launch_bounds__(MS_THREADS)
 k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
            const double *__restrict__ X, const double *__restrict__ gamma,
            const double *__restrict__ post, const double *__restrict__ mean,
-           double *__restrict__ part_mu, double *__restrict__ part_var)
+           double *__restrict__ part_mu, double *__restrict__ part_var,
+           const int *__restrict__ only_if)
 {
     extern __shared__ double lds[];
+    if (only_if && only_if[0] == 0) return; // matrix-core tier: nothing is ill-conditioned
     const int G = N * M, D1 = D + 1;
     const long long E = (long long)G * D1;
     const int tid = threadIdx.x;
@@ -517,8 +519,10 @@ k_reduce_utt(int N, int U, int delta, const double *__restrict__ part_xi,
 __global__ void __launch_bounds__(RD_THREADS)
 k_reduce_mix(int N, int M, int D, int P, const double *__restrict__ part_mu,
              const double *__restrict__ part_var, double *__restrict__ num_c,
-             double *__restrict__ num_mu, double *__restrict__ num_var)
+             double *__restrict__ num_mu, double *__restrict__ num_var,
+             const int *__restrict__ only_if)
 {
+    if (only_if && only_if[0] == 0) return;
     const int G = N * M, D1 = D + 1;
     const long long E = (long long)G * D1;
     long long e = (long long)blockIdx.x * RD_THREADS + threadIdx.x;

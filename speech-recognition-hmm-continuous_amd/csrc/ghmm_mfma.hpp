@@ -29,15 +29,53 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr double COND_MAX = 1.0e4; // expanded-form error ~ 4*eps*cond  (<= ~5e-12)
 constexpr int EM_WAVES = 4;        // waves per emission block
 
+// Offsets for the expanded forms: offs[c][DP] = mean of the means of tile c's real
+// Gaussians (0 beyond D); oglob[d] = mean of all means (grid = NT + D blocks).
+__global__ void __launch_bounds__(64)
+k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__restrict__ mean,
+                  double *__restrict__ offs, double *__restrict__ oglob)
+{
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (q < NT) {
+        for (int d = t; d < DP; d += 64) {
+            double o = 0.0;
+            int cnt = 0;
+            if (d < D)
+                for (int jj = 0; jj < 16; jj++) {
+                    int gq = q * 16 + jj, ii = gq / Mp, mm = gq % Mp;
+                    if (ii < N && mm < M) {
+                        o += mean[((size_t)ii * M + mm) * D + d];
+                        cnt++;
+                    }
+                }
+            offs[(size_t)q * DP + d] = cnt ? o / cnt : 0.0;
+        }
+    } else {
+        __shared__ double sh[64];
+        const int d = q - NT, G = N * M;
+        double o = 0.0;
+        for (int g = t; g < G; g += 64) o += mean[(size_t)g * D + d];
+        sh[t] = o;
+        __syncthreads();
+        for (int k = 32; k > 0; k >>= 1) {
+            if (t < k) sh[t] += sh[t + k];
+            __syncthreads();
+        }
+        if (t == 0) oglob[d] = sh[0] / (double)G;
+    }
+}
+
 // One thread per padded Gaussian gp = 16*c + j (state gp / Mp, mixture gp % Mp).
 //   Wm[c][s][lane]  B fragments in lane order: row kk = 4s + (lane>>4), col lane&15
 //                   rows 0..DP-1 multiply [x'_0..x'_{D-1}, 1, 0..], rows DP.. multiply x'^2
-//   offs[c][DP]     tile offset (0 beyond D);  wkp[gp], gmap[gp] (-1 = padding), condp[gp]
+//   wkp[gp], gmap[gp] (-1 = padding); condp / condg = sum_d inv_d mu'_d^2 with the tile
+//   offset / the global offset (the cancellation measure of the two expanded forms)
 __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
                                const double *__restrict__ mean, const double *__restrict__ inv_var,
-                               const double *__restrict__ wk, double *__restrict__ Wm,
-                               double *__restrict__ offs, double *__restrict__ wkp,
-                               int *__restrict__ gmap, double *__restrict__ condp)
+                               const double *__restrict__ wk, const double *__restrict__ offs,
+                               const double *__restrict__ oglob, double *__restrict__ Wm,
+                               double *__restrict__ wkp, int *__restrict__ gmap,
+                               double *__restrict__ condp, double *__restrict__ condg)
 {
     const int gp = blockIdx.x * blockDim.x + threadIdx.x;
     if (gp >= NT * 16) return;
@@ -48,27 +86,16 @@ __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
     gmap[gp] = g;
     wkp[gp] = real ? wk[g] : 0.0;
     double *Wc = Wm + (size_t)c * KS * 64;
-    double c0 = 0.0;
+    double c0 = 0.0, cg = 0.0;
     for (int d = 0; d < DP; d++) {
-        double o = 0.0;
-        if (d < D) {
-            int cnt = 0;
-            for (int jj = 0; jj < 16; jj++) {
-                int gq = c * 16 + jj, ii = gq / Mp, mm = gq % Mp;
-                if (ii < N && mm < M) {
-                    o += mean[((size_t)ii * M + mm) * D + d];
-                    cnt++;
-                }
-            }
-            o = cnt ? o / cnt : 0.0;
-        }
-        if (j == 0) offs[(size_t)c * DP + d] = o;
         double bc = 0.0, ac = 0.0;
         if (real && d < D) {
-            double mu = mean[(size_t)g * D + d] - o, iv = inv_var[(size_t)g * D + d];
+            const double mraw = mean[(size_t)g * D + d], iv = inv_var[(size_t)g * D + d];
+            const double mu = mraw - offs[(size_t)c * DP + d], mg = mraw - oglob[d];
             bc = mu * iv;
             ac = -0.5 * iv;
             c0 += mu * mu * iv;
+            cg += mg * mg * iv;
         }
         if (d != D) Wc[(d >> 2) * 64 + (d & 3) * 16 + j] = bc;
         const int k2 = DP + d;
@@ -76,6 +103,21 @@ __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
     }
     Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * c0 : 0.0; // multiplies the constant 1
     condp[gp] = real ? c0 : 0.0;
+    condg[gp] = real ? cg : 0.0;
+}
+
+// anyflag[0] = 1 when some Gaussian is too ill-conditioned for the expanded statistics
+// (then the vector-ALU k_mixstats runs as well and supplies those Gaussians' sums)
+__global__ void k_any_flag(int n, const double *__restrict__ condg, int *__restrict__ anyflag)
+{
+    __shared__ int sh;
+    if (threadIdx.x == 0) sh = 0;
+    __syncthreads();
+    int f = 0;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) f |= condg[k] > COND_MAX;
+    if (f) atomicOr(&sh, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) anyflag[0] = sh;
 }
 
 // calc_symbol_probab + calc_gaus (TF:1749-1841) for 16 frames x TC Gaussian tiles per
@@ -199,6 +241,152 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                 }
             }
         }
+    }
+}
+
+
+// ---------------------------------------------------------------- mixstats
+// calc_mix_param (TF:1691-1727) as a matrix product over the time axis:
+//     S[g][e] = sum_t w_t(g) * Fext_t[e],  w_t(g) = gamma_t(state(g)) * post_t(g) (TF:1706-1711)
+// with Fext = [x'_0..x'_{D-1}, 1, 0.., x'^2_0..x'^2_{D-1}, 0..] (x' = x - oglob), so that
+//     num_c = S[.][D],  num_mu_d = S_d + oglob_d num_c,
+//     num_var_d = sum w (x_d - mu_d)^2 = S_{DP+d} - 2 mu'_d S_d + mu'_d^2 num_c   (old mean, TF:1720)
+// A = w^T (16 Gaussians x 4 frames), B = Fext (4 frames x 16 features).  One wave owns
+// CT x NE accumulator tiles and a contiguous range of frames; operands come straight
+// from HBM/L2 in 128-B row segments, prefetched one k-step ahead.  The four waves of
+// a block fold their tiles through LDS in wave order and the block writes ONE partial;
+// k_sum_partials adds the partials in block order (bitwise reproducible).
+constexpr int MSM_WAVES = 4;
+
+template <int CT, int NE>
+__global__ void __launch_bounds__(MSM_WAVES *WAVE, 1)
+k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
+                const double *__restrict__ X, const double *__restrict__ gamma,
+                const double *__restrict__ post, const int *__restrict__ gmap,
+                const double *__restrict__ oglob, double *__restrict__ part)
+{
+    extern __shared__ double lds[]; // [CT*NE*4][64]
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int G = N * M, ES = NE * 16;
+    const int c0 = blockIdx.y * CT;
+    int gmA[CT], stA[CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        const int gp = (c0 + c) * 16 + j;
+        gmA[c] = (c0 + c < NT) ? gmap[gp] : -1;
+        stA[c] = gp / Mp;
+    }
+    int dn[NE], kind[NE];
+    double on[NE];
+#pragma unroll
+    for (int n = 0; n < NE; n++) {
+        const int e = 16 * n + j, k = e / DP, d = e - k * DP;
+        kind[n] = (k < 2 && d < D) ? k : ((k == 0 && d == D) ? 2 : 3); // 0 x', 1 x'^2, 2 one, 3 zero
+        dn[n] = (k < 2 && d < D) ? d : 0;
+        on[n] = (k < 2 && d < D) ? oglob[d] : 0.0;
+    }
+    v4d acc[CT][NE];
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+#pragma unroll
+        for (int n = 0; n < NE; n++) acc[c][n] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // this wave's frames: ranges of whole k-steps (4 frames), dealt evenly
+    const long long nwaves = (long long)gridDim.x * MSM_WAVES;
+    const long long wi = (long long)blockIdx.x * MSM_WAVES + w;
+    const long long steps = (F + 3) / 4;
+    const long long s0 = steps * wi / nwaves, s1 = steps * (wi + 1) / nwaves;
+
+    double wv[CT], xv[NE], wn[CT], xn[NE];
+    auto load = [&](long long st, double *wo, double *xo) {
+        const long long t = st * 4 + kq;
+        const bool ok = t < F;
+#pragma unroll
+        for (int c = 0; c < CT; c++)
+            wo[c] = (ok && gmA[c] >= 0) ? gamma[t * N + stA[c]] * post[t * G + gmA[c]] : 0.0;
+#pragma unroll
+        for (int n = 0; n < NE; n++) xo[n] = (ok && kind[n] < 2) ? X[t * D + dn[n]] : 0.0;
+    };
+    if (s0 < s1) load(s0, wv, xv);
+    for (long long st = s0; st < s1; st++) {
+        if (st + 1 < s1) load(st + 1, wn, xn);
+        double ft[NE];
+#pragma unroll
+        for (int n = 0; n < NE; n++) {
+            const double xo = xv[n] - on[n];
+            ft[n] = kind[n] == 0 ? xo : (kind[n] == 1 ? xo * xo : (kind[n] == 2 ? 1.0 : 0.0));
+        }
+#pragma unroll
+        for (int c = 0; c < CT; c++)
+#pragma unroll
+            for (int n = 0; n < NE; n++)
+                acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], ft[n], acc[c][n], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; c++) wv[c] = wn[c];
+#pragma unroll
+        for (int n = 0; n < NE; n++) xv[n] = xn[n];
+    }
+    // fold the block's waves in wave order, then write the block's partial
+    for (int ww = 0; ww < MSM_WAVES; ww++) {
+        if (w == ww) {
+#pragma unroll
+            for (int c = 0; c < CT; c++)
+#pragma unroll
+                for (int n = 0; n < NE; n++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int li = ((c * NE + n) * 4 + r) * 64 + l;
+                        if (ww == 0) lds[li] = acc[c][n][r];
+                        else if (ww < MSM_WAVES - 1) lds[li] += acc[c][n][r];
+                        else {
+                            const int gp = (c0 + c) * 16 + kq + 4 * r;
+                            if (c0 + c < NT)
+                                part[((size_t)blockIdx.x * NT * 16 + gp) * ES + 16 * n + j] =
+                                    lds[li] + acc[c][n][r];
+                        }
+                    }
+        }
+        __syncthreads();
+    }
+}
+
+// sums[k] = sum_p part[p][k], p ascending within 4 interleaved slices, then a fixed tree
+__global__ void __launch_bounds__(256)
+k_sum_partials(long long n, int P, const double *__restrict__ part, double *__restrict__ sums)
+{
+    __shared__ double sh[256];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long k = (long long)blockIdx.x * 64 + e;
+    double v = 0.0;
+    if (k < n)
+        for (int p = sl; p < P; p += 4) v += part[(size_t)p * n + k];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    if (sl == 0 && k < n) sums[k] = (sh[e] + sh[64 + e]) + (sh[128 + e] + sh[192 + e]);
+}
+
+// expanded sums -> the reference's accumulators (layout of include/ghmm.h); Gaussians
+// flagged by condg keep the sums the vector-ALU kernel produced for them
+__global__ void __launch_bounds__(256)
+k_finish_mix(int N, int M, int D, int DP, int NT, int ES, const double *__restrict__ sums,
+             const int *__restrict__ gmap, const double *__restrict__ condg,
+             const double *__restrict__ oglob, const double *__restrict__ mean,
+             double *__restrict__ num_c, double *__restrict__ num_mu, double *__restrict__ num_var)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D1 = D + 1;
+    if (k >= (long long)NT * 16 * D1) return;
+    const int gp = (int)(k / D1), d = (int)(k - (long long)gp * D1);
+    const int g = gmap[gp];
+    if (g < 0 || condg[gp] > COND_MAX) return;
+    const double *S = sums + (size_t)gp * ES;
+    const double S0 = S[D];
+    if (d == D) {
+        num_c[g] = S0;
+    } else {
+        const double o = oglob[d], mu = mean[(size_t)g * D + d] - o;
+        num_mu[(size_t)g * D + d] = S[d] + o * S0;
+        num_var[(size_t)g * D + d] = (S[DP + d] - 2.0 * mu * S[d]) + mu * mu * S0;
     }
 }
 
