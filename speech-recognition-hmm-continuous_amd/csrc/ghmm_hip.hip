@@ -55,9 +55,10 @@ struct ghmm_ctx {
     // workspace (grown on demand, never shrunk)
     size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
            cap_lognorm = 0, cap_loglik = 0, cap_pxi = 0, cap_pdena = 0, cap_pdenc = 0, cap_pmu = 0,
-           cap_pvar = 0, cap_psi = 0, cap_path = 0, cap_pm = 0, cap_sums = 0;
+           cap_pvar = 0, cap_psi = 0, cap_path = 0, cap_pm = 0, cap_sums = 0, cap_sinv = 0, cap_sink = 0;
     double *b = nullptr, *post = nullptr, *alpha = nullptr, *beta = nullptr, *gamma = nullptr;
-    double *scale = nullptr, *lognorm = nullptr, *loglik = nullptr;
+    double *scale = nullptr, *sinv = nullptr, *lognorm = nullptr, *loglik = nullptr;
+    double *sink = nullptr; // 64 doubles that idle lanes read and write instead of branching
     double *part_xi = nullptr, *part_dena = nullptr, *part_denc = nullptr;
     double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr, *sums = nullptr;
     unsigned char *psi = nullptr;
@@ -222,7 +223,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     void *bufs[] = {ctx->b,       ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
-                    ctx->part_m,  ctx->sums};
+                    ctx->part_m,  ctx->sums,      ctx->sinv,      ctx->sink};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &t : ctx->kt) {
@@ -383,7 +384,7 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
         if (TC > m->NT) TC = m->NT;
         m->TC = TC;
         m->em_lds = (size_t)TC * per_tile + (size_t)EM_WAVES * 16 * (m->DP + 1) * 8;
-        m->mfma_ok = TC >= m->tps && TC > 0 && m->em_lds <= 150 * 1024;
+        m->mfma_ok = TC >= m->tps && TC > 0 && m->em_lds <= 150 * 1024 && 16 * m->DP <= 64 * EM_XR;
         if (m->mfma_ok) {
             size_t nw = (size_t)m->NT * (m->DP / 2) * 64;
             if ((rc = dev_alloc(&m->Wm, nw)) || (rc = dev_alloc(&m->offs, (size_t)m->NT * m->DP)) ||
@@ -648,6 +649,11 @@ static int ws_frames(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c, b
     if ((rc = dev_grow(&ctx->b, &ctx->cap_b, F * N))) return rc;
     if (want_post && (rc = dev_grow(&ctx->post, &ctx->cap_post, F * G))) return rc;
     if ((rc = dev_grow(&ctx->scale, &ctx->cap_scale, F))) return rc;
+    if ((rc = dev_grow(&ctx->sinv, &ctx->cap_sinv, F))) return rc;
+    if (!ctx->sink) {
+        if ((rc = dev_grow(&ctx->sink, &ctx->cap_sink, (size_t)WAVE))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->sink, 0, WAVE * sizeof(double), ctx->stream));
+    }
     if ((rc = dev_grow(&ctx->lognorm, &ctx->cap_lognorm, F))) return rc;
     if ((rc = dev_grow(&ctx->loglik, &ctx->cap_loglik, (size_t)c->U))) return rc;
     ctx->F = c->F;
@@ -758,10 +764,10 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
         kscope ks(ctx, GHMM_K_FORWARD);
         if (L == 16)
             hipLaunchKernelGGL(k_forward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ln, ctx->loglik);
+                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink);
         else
             hipLaunchKernelGGL(k_forward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ln, ctx->loglik);
+                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink);
     }
     return launch_ok("k_forward");
 }
@@ -777,12 +783,12 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
         kscope ks(ctx, GHMM_K_BACKWARD);
         if (L == 16)
             hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
-                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc);
+                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
+                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
         else
             hipLaunchKernelGGL(k_backward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
-                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc);
+                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
+                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
     }
     return launch_ok("k_backward");
 }

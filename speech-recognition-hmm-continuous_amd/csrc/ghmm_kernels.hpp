@@ -151,11 +151,97 @@ k_emission(int N, int M, int D, long long F, const double *__restrict__ X,
 // ------------------------------------------------------------ group helpers
 // A "group" is L consecutive lanes (L = 16 or 64) that own one utterance, lane i =
 // state i.  Cross-lane traffic stays inside the group.
+// For L = 16 a group is one DPP row: shifts and the butterfly sum are register moves
+// (v_mov_b32_dpp), not LDS-crossbar shuffles (ds_bpermute) — they sit on the serial
+// critical path of every time step.
+template <int CTRL> __device__ inline double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true); // out-of-row source -> 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111;
+constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+
 template <int L> __device__ inline double group_sum(double v)
 {
+    if (L == 16) {
+        // rotate-and-add: every lane of the row ends with the same bits (each level adds
+        // the same unordered pair on both partners)
+        v += dpp_f64<DPP_ROW_ROR8>(v);
+        v += dpp_f64<DPP_ROW_ROR4>(v);
+        v += dpp_f64<DPP_ROW_ROR2>(v);
+        v += dpp_f64<DPP_ROW_ROR1>(v);
+        return v;
+    }
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, L);
     return v;
+}
+// value of lane i-1 (0 for the first lane of the group) / lane i+1 (0 for the last)
+template <int L> __device__ inline double group_up1(double v)
+{
+    if (L == 16) return dpp_f64<DPP_ROW_SHR1>(v);
+    double r = __shfl_up(v, 1, L);
+    return (threadIdx.x % L) ? r : 0.0;
+}
+template <int L> __device__ inline double group_down1(double v)
+{
+    if (L == 16) return dpp_f64<DPP_ROW_SHL1>(v);
+    double r = __shfl_down(v, 1, L);
+    return (threadIdx.x % L) != L - 1 ? r : 0.0;
+}
+// sum over the Mp (power of two <= 16) adjacent lanes that hold one state's mixtures
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141,
+              DPP_ROW_MIRROR = 0x140;
+__device__ inline double segment_sum(double v, int Mp)
+{
+    if (Mp >= 2) v += dpp_f64<DPP_QUAD_XOR1>(v);
+    if (Mp >= 4) v += dpp_f64<DPP_QUAD_XOR2>(v);
+    if (Mp >= 8) v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    if (Mp >= 16) v += dpp_f64<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+// exp(x) for the emission epilogue: x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor
+// polynomial (truncation 4e-18), v_ldexp_f64 for 2^k (gradual underflow to 0 like libm).
+// Branch-free; NaN stays NaN; within ~1 ulp of glibc's exp on (-750, 1].
+__device__ inline double exp_emis(double x)
+{
+    x = x < -750.0 ? -750.0 : x;
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;           // 1/13!
+    p = fma(p, r, 2.08767569878680989792e-09);   // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);
+    p = fma(p, r, 2.75573192239858906526e-07);
+    p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05);
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+// 1/s: hardware reciprocal + two Newton steps (<= 1 ulp from the IEEE quotient the
+// reference computes, TF:1414/1436) for normal s; the exact division otherwise so that
+// s = 0 still yields the reference's inf -> NaN cascade
+__device__ inline double recip_scale(double s)
+{
+    if (s >= 1.0e-290 && s <= 1.0e290) {
+        double r = __builtin_amdgcn_rcp(s);
+        r = fma(r, fma(-s, r, 1.0), r);
+        r = fma(r, fma(-s, r, 1.0), r);
+        return r;
+    }
+    return 1.0 / s;
 }
 
 constexpr int PF = 8; // frames of b / alpha prefetched ahead of the serial recursion
@@ -166,12 +252,109 @@ constexpr int PF = 8; // frames of b / alpha prefetched ahead of the serial recu
 // serial, utterances are the parallel axis (SURVEY.md §5 "long-context").
 //   alpha_t(i) = (sum_j alpha^_{t-1}(j) a_ji) b_i(t);  c_t = 1/sum_i alpha_t(i);  alpha^ = alpha c_t
 //   log P = -sum_t log c_t + log alpha^_{T-1}(N-1)   [+ sum_t lognorm_t in robust mode]
+// The loop body is branch-free: lanes that own no output store into a sink, the
+// reciprocal is a select between Newton's result and the raw v_rcp_f64 (0 / inf / tiny
+// sums, where the reference's 1/0 -> NaN cascade must survive), and A's band structure
+// is a template parameter chosen once per wave.
+__device__ inline double recip_select(double s)
+{
+    const double r0 = __builtin_amdgcn_rcp(s); // inf for 0, 0 for inf, like 1.0/s
+    double r = fma(r0, fma(-s, r0, 1.0), r0);
+    r = fma(r, fma(-s, r, 1.0), r);
+    return (s >= 1.0e-290 && s <= 1.0e290) ? r : r0;
+}
+
+template <int L, bool BANDED> struct fwd_state {
+    double a, a_self, a_prev;
+    double acol[BANDED ? 1 : L];
+    int N;
+    __device__ inline void step(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
+    {
+        double aux;
+        if (BANDED) {
+            aux = group_up1<L>(a) * a_prev + a * a_self;
+        } else {
+            aux = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; j++)
+                if (j < N) aux += __shfl(a, j, L) * acol[j];
+        }
+        const double v = aux * bt;
+        const double s = group_sum<L>(v);
+        const double c = recip_select(s);
+        a = v * c;
+        *pa = a;
+        *pcs = (i == 0) ? c : s;
+    }
+};
+
+template <int L, bool BANDED>
+__device__ inline double forward_run(int N, int T, int i, bool act, const double *__restrict__ A,
+                                     const double *__restrict__ bu, double *__restrict__ au,
+                                     double *__restrict__ su, double *__restrict__ si,
+                                     double *__restrict__ sink)
+{
+    fwd_state<L, BANDED> st;
+    st.N = N;
+    st.a_self = act ? A[i * N + i] : 0.0;
+    st.a_prev = (act && i > 0) ? A[(i - 1) * N + i] : 0.0;
+    if (!BANDED) {
+#pragma unroll
+        for (int j = 0; j < L; j++) st.acol[BANDED ? 0 : j] = (act && j < N) ? A[j * N + i] : 0.0;
+    }
+    // per-lane store cursors: alpha slot (stride N) or the sink (stride 0); lane 0 writes
+    // c_t, lane 1 writes 1/c_t = sum_i alpha_t(i), the rest write the sink
+    double *pa = act ? au + i : sink;
+    const int da = act ? N : 0;
+    double *pcs = (i == 0) ? su : (i == 1 ? si : sink);
+    const int dc = (i < 2) ? 1 : 0;
+    const double *pb = act ? bu + i : sink; // b cursor (sink holds finite junk for idle lanes)
+    const int db = act ? N : 0;
+
+    // t = 0
+    {
+        const double a0 = ((i == 0) ? 1.0 : 0.0) * (act ? *pb : 0.0);
+        const double s = group_sum<L>(a0);
+        const double c = recip_select(s);
+        st.a = a0 * c;
+        *pa = st.a;
+        *pcs = (i == 0) ? c : s;
+        pa += da; pcs += dc; pb += db;
+    }
+    double bq[PF];
+    int t = 1;
+#pragma unroll
+    for (int k = 0; k < PF; k++) bq[k] = (t + k < T) ? pb[(size_t)k * db] : 0.0;
+    for (; t + PF <= T; t += PF) {
+        double bn[PF];
+        const double *pn = pb + (size_t)PF * db;
+#pragma unroll
+        for (int k = 0; k < PF; k++) bn[k] = (t + PF + k < T) ? pn[(size_t)k * db] : 0.0;
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            st.step(bq[k], pa, pcs, i);
+            pa += da; pcs += dc;
+        }
+        pb = pn;
+#pragma unroll
+        for (int k = 0; k < PF; k++) bq[k] = bn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; k++)
+        if (t + k < T) {
+            st.step(bq[k], pa, pcs, i);
+            pa += da; pcs += dc;
+        }
+    return st.a;
+}
+
 template <int L>
 __global__ void __launch_bounds__(WAVE)
 k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__ b,
           const long long *__restrict__ off, double *__restrict__ alpha,
-          double *__restrict__ scale, const double *__restrict__ lognorm,
-          double *__restrict__ loglik)
+          double *__restrict__ scale, double *__restrict__ sinv,
+          const double *__restrict__ lognorm, double *__restrict__ loglik,
+          double *__restrict__ sink)
 {
     const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
@@ -183,59 +366,17 @@ k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__
         return;
     }
     const bool act = i < N;
-    double acol[L]; // column i of A: acol[j] = a_ji
-#pragma unroll
-    for (int j = 0; j < L; j++) acol[j] = (act && j < N) ? A[j * N + i] : 0.0;
     bool offband = false;
-#pragma unroll
-    for (int j = 0; j < L; j++) offband |= (acol[j] != 0.0 && j != i && j != i - 1);
+    for (int j = 0; j < N; j++)
+        offband |= act && (A[j * N + i] != 0.0 && j != i && j != i - 1);
     const bool banded = !__any(offband);
-    const double a_self = act ? A[i * N + i] : 0.0;
-    const double a_prev = (act && i > 0) ? A[(i - 1) * N + i] : 0.0;
-
-    const double *bu = b + f0 * N;
-    double *au = alpha + f0 * N;
-    double *su = scale + f0;
-
-    double bq[PF], bn[PF];
-    double a = ((i == 0) ? 1.0 : 0.0) * (act ? bu[i] : 0.0);
-    {
-        double s = group_sum<L>(a);
-        double c = 1.0 / s;
-        a *= c;
-        if (act) au[i] = a;
-        if (i == 0) su[0] = c;
-    }
-#pragma unroll
-    for (int k = 0; k < PF; k++) bq[k] = (act && 1 + k < T) ? bu[(size_t)(1 + k) * N + i] : 0.0;
-    for (int tb = 1; tb < T; tb += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; k++)
-            bn[k] = (act && tb + PF + k < T) ? bu[(size_t)(tb + PF + k) * N + i] : 0.0;
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int t = tb + k;
-            if (t < T) {
-                double aux = 0.0;
-                if (banded) {
-                    double up = __shfl_up(a, 1, L);
-                    aux = (i > 0 ? up * a_prev : 0.0) + a * a_self;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < L; j++)
-                        if (j < N) aux += __shfl(a, j, L) * acol[j];
-                }
-                double v = aux * bq[k];
-                double s = group_sum<L>(v);
-                double c = 1.0 / s;
-                a = v * c;
-                if (act) au[(size_t)t * N + i] = a;
-                if (i == 0) su[t] = c;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PF; k++) bq[k] = bn[k];
-    }
+    double *su = scale + f0, *si = sinv + f0;
+    double *snk = sink + (threadIdx.x & (WAVE - 1));
+    double a;
+    if (banded)
+        a = forward_run<L, true>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk);
+    else
+        a = forward_run<L, false>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk);
     // log P: the T logs are spread over the group's lanes instead of a serial loop
     __threadfence_block();
     double lp = 0.0;
@@ -256,14 +397,140 @@ k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__
 //   xi[u][i][o] = sum_{t<T-1} alpha^_t(i) a_{i,i+o} b_{i+o}(t+1) beta^_{t+1}(i+o),  o = 0..delta
 //   dena[u][i] = sum_{t<T-1} gamma_t(i);   denc[u][i] = sum_{t<T} gamma_t(i)
 // Per-utterance partial sums are written out and added in utterance order by
-// k_reduce (bitwise reproducible; no atomics).
+// k_reduce_utt (bitwise reproducible; no atomics).  gamma uses 1/c_t = sum_i alpha_t(i)
+// kept by the forward pass instead of a division.
+template <int L, bool BANDED> struct bwd_state {
+    double be, a_self, a_next, dena, denc;
+    double arow[BANDED ? 1 : L];
+    double aband[MAX_DELTA + 1], xi[MAX_DELTA + 1];
+    int N, delta;
+    // one step t (descending): bnext = b_i(t+1), al = alpha^_t(i), c = c_t, sv = 1/c_t
+    __device__ inline void step(double bnext, double al, double c, double sv,
+                                double *__restrict__ pbe, double *__restrict__ pg, int i)
+    {
+        const double w = be * bnext; // beta^_{t+1}(i) b_i(t+1) on lane i
+        const double wd = group_down1<L>(w);
+        double aux;
+        if (BANDED) {
+            aux = a_self * w + a_next * wd;
+        } else {
+            aux = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; j++)
+                if (j < N) aux += arow[j] * __shfl(w, j, L);
+        }
+        xi[0] += al * aband[0] * w;
+        xi[1] += al * aband[1] * wd;
+#pragma unroll
+        for (int o = 2; o <= MAX_DELTA; o++)
+            if (o <= delta) {
+                double wj = __shfl_down(w, o, L);
+                xi[o] += (i + o < N) ? al * aband[o] * wj : 0.0;
+            }
+        be = aux * c;
+        const double g = al * be * sv;
+        *pbe = be;
+        *pg = g;
+        dena += g;
+        denc += g;
+    }
+};
+
+template <int L, bool BANDED>
+__device__ inline void backward_run(int N, int T, int delta, int i, bool act, int u,
+                                    const double *__restrict__ A, const double *__restrict__ bu,
+                                    const double *__restrict__ au, const double *__restrict__ su,
+                                    const double *__restrict__ si, double *__restrict__ beu,
+                                    double *__restrict__ gu, double *__restrict__ part_xi,
+                                    double *__restrict__ part_dena, double *__restrict__ part_denc,
+                                    double *__restrict__ sink)
+{
+    bwd_state<L, BANDED> st;
+    st.N = N;
+    st.delta = delta;
+    st.dena = st.denc = 0.0;
+    st.a_self = act ? A[i * N + i] : 0.0;
+    st.a_next = (act && i + 1 < N) ? A[i * N + i + 1] : 0.0;
+    if (!BANDED) {
+#pragma unroll
+        for (int j = 0; j < L; j++) st.arow[BANDED ? 0 : j] = (act && j < N) ? A[i * N + j] : 0.0;
+    }
+#pragma unroll
+    for (int o = 0; o <= MAX_DELTA; o++) {
+        st.aband[o] = (act && i + o < N && o <= delta) ? A[i * N + i + o] : 0.0;
+        st.xi[o] = 0.0;
+    }
+    const int dn = act ? N : 0;
+    // cursors at t = T-1 (lanes without a state read/write the sink, stride 0)
+    const double *pa = act ? au + (size_t)(T - 1) * N + i : sink;
+    const double *pb = act ? bu + (size_t)(T - 1) * N + i : sink;
+    double *pbe = act ? beu + (size_t)(T - 1) * N + i : sink;
+    double *pg = act ? gu + (size_t)(T - 1) * N + i : sink;
+    const double *pc = su + (T - 1), *ps = si + (T - 1);
+    {
+        const double cT = *pc;
+        st.be = (i == N - 1) ? 1.0 * cT : 0.0;
+        const double g = (act ? *pa : 0.0) * st.be * *ps;
+        *pbe = st.be;
+        *pg = g;
+        st.denc += g;
+    }
+    // queues for step t (descending from T-2): b[t+1], alpha[t], c[t], 1/c[t]
+    double qb[PF], qa[PF], qc[PF], qs[PF];
+    int t = T - 2;
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        const bool ok = t - k >= 0;
+        qb[k] = ok ? *(pb - (size_t)k * dn) : 0.0;
+        qa[k] = ok ? *(pa - (size_t)(k + 1) * dn) : 0.0;
+        qc[k] = ok ? *(pc - (k + 1)) : 1.0;
+        qs[k] = ok ? *(ps - (k + 1)) : 1.0;
+    }
+    pbe -= dn; pg -= dn;
+    for (; t - PF + 1 >= 0; t -= PF) {
+        double nb[PF], na[PF], nc[PF], ns[PF];
+        pb -= (size_t)PF * dn; pa -= (size_t)PF * dn; pc -= PF; ps -= PF;
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const bool ok = t - PF - k >= 0;
+            nb[k] = ok ? *(pb - (size_t)k * dn) : 0.0;
+            na[k] = ok ? *(pa - (size_t)(k + 1) * dn) : 0.0;
+            nc[k] = ok ? *(pc - (k + 1)) : 1.0;
+            ns[k] = ok ? *(ps - (k + 1)) : 1.0;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            st.step(qb[k], qa[k], qc[k], qs[k], pbe, pg, i);
+            pbe -= dn; pg -= dn;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            qb[k] = nb[k]; qa[k] = na[k]; qc[k] = nc[k]; qs[k] = ns[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; k++)
+        if (t - k >= 0) {
+            st.step(qb[k], qa[k], qc[k], qs[k], pbe, pg, i);
+            pbe -= dn; pg -= dn;
+        }
+    // gamma_{T-1} belongs to den_c only (TF:1618 sums t < T-1, TF:1660 sums t < T):
+    // dena was accumulated for t <= T-2 only, as required
+    if (act) {
+        for (int o = 0; o <= delta; o++) part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o] = st.xi[o];
+        part_dena[(size_t)u * N + i] = st.dena;
+        part_denc[(size_t)u * N + i] = st.denc;
+    }
+}
+
 template <int L>
 __global__ void __launch_bounds__(WAVE)
 k_backward(int N, int U, int delta, const double *__restrict__ A, const double *__restrict__ b,
            const long long *__restrict__ off, const double *__restrict__ alpha,
-           const double *__restrict__ scale, double *__restrict__ beta,
-           double *__restrict__ gamma, double *__restrict__ part_xi,
-           double *__restrict__ part_dena, double *__restrict__ part_denc)
+           const double *__restrict__ scale, const double *__restrict__ sinv,
+           double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ part_xi,
+           double *__restrict__ part_dena, double *__restrict__ part_denc,
+           double *__restrict__ sink)
 {
     const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
@@ -271,110 +538,28 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     const bool act = i < N;
-    double xi[MAX_DELTA + 1];
-#pragma unroll
-    for (int o = 0; o <= MAX_DELTA; o++) xi[o] = 0.0;
-    double dena = 0.0, denc = 0.0;
-    if (T > 0) {
-        double arow[L]; // row i of A
-#pragma unroll
-        for (int j = 0; j < L; j++) arow[j] = (act && j < N) ? A[i * N + j] : 0.0;
-        bool offband = false;
-#pragma unroll
-        for (int j = 0; j < L; j++) offband |= (arow[j] != 0.0 && j != i && j != i + 1);
-        const bool banded = !__any(offband);
-        const double a_self = act ? A[i * N + i] : 0.0;
-        const double a_next = (act && i + 1 < N) ? A[i * N + i + 1] : 0.0;
-        double aband[MAX_DELTA + 1]; // a_{i,i+o}
-#pragma unroll
-        for (int o = 0; o <= MAX_DELTA; o++)
-            aband[o] = (act && i + o < N && o <= delta) ? A[i * N + i + o] : 0.0;
-
-        const double *bu = b + f0 * N;
-        const double *au = alpha + f0 * N;
-        const double *su = scale + f0;
-        double *beu = beta + f0 * N;
-        double *gu = gamma + f0 * N;
-
-        // t = T-1
-        double cT = su[T - 1];
-        double be = (i == N - 1) ? 1.0 * cT : 0.0;
-        {
-            double al = act ? au[(size_t)(T - 1) * N + i] : 0.0;
-            double g = al * be / cT;
-            if (act) {
-                beu[(size_t)(T - 1) * N + i] = be;
-                gu[(size_t)(T - 1) * N + i] = g;
-            }
-            denc += g;
+    if (T <= 0) {
+        if (act) {
+            for (int o = 0; o <= delta; o++) part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o] = 0.0;
+            part_dena[(size_t)u * N + i] = 0.0;
+            part_denc[(size_t)u * N + i] = 0.0;
         }
-        // queues for step t (descending): b[t+1][i], alpha[t][i], c[t]
-        double qb[PF], qa[PF], qc[PF], nb[PF], na[PF], nc[PF];
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int t = T - 2 - k;
-            const bool ok = t >= 0;
-            qb[k] = (act && ok) ? bu[(size_t)(t + 1) * N + i] : 0.0;
-            qa[k] = (act && ok) ? au[(size_t)t * N + i] : 0.0;
-            qc[k] = ok ? su[t] : 1.0;
-        }
-        for (int tb = T - 2; tb >= 0; tb -= PF) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int t = tb - PF - k;
-                const bool ok = t >= 0;
-                nb[k] = (act && ok) ? bu[(size_t)(t + 1) * N + i] : 0.0;
-                na[k] = (act && ok) ? au[(size_t)t * N + i] : 0.0;
-                nc[k] = ok ? su[t] : 1.0;
-            }
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int t = tb - k;
-                if (t >= 0) {
-                    const double w = be * qb[k]; // beta^_{t+1}(i) b_i(t+1), lane i
-                    double aux = 0.0;
-                    if (banded) {
-                        // upper-bidiagonal A: only j = i and j = i+1 contribute
-                        double dn = __shfl_down(w, 1, L);
-                        aux = a_self * w + (i + 1 < N ? a_next * dn : 0.0);
-                    } else {
-                        // general form: sum_j a_ij w_j, ascending j
-#pragma unroll
-                        for (int j = 0; j < L; j++)
-                            if (j < N) aux += arow[j] * __shfl(w, j, L);
-                    }
-                    // xi band sums
-#pragma unroll
-                    for (int o = 0; o <= MAX_DELTA; o++)
-                        if (o <= delta) {
-                            double wj = (o == 0) ? w : __shfl_down(w, o, L);
-                            if (i + o < N) xi[o] += qa[k] * aband[o] * wj;
-                        }
-                    be = aux * qc[k];
-                    double g = qa[k] * be / qc[k];
-                    if (act) {
-                        beu[(size_t)t * N + i] = be;
-                        gu[(size_t)t * N + i] = g;
-                    }
-                    dena += g;
-                    denc += g;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                qb[k] = nb[k];
-                qa[k] = na[k];
-                qc[k] = nc[k];
-            }
-        }
+        return;
     }
-    if (act) {
-        for (int o = 0; o <= delta; o++) part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o] = xi[o];
-        part_dena[(size_t)u * N + i] = dena;
-        part_denc[(size_t)u * N + i] = denc;
-    }
+    bool offband = false;
+    for (int j = 0; j < N; j++)
+        offband |= act && (A[i * N + j] != 0.0 && j != i && j != i + 1);
+    const bool banded = !__any(offband);
+    double *snk = sink + (threadIdx.x & (WAVE - 1));
+    if (banded)
+        backward_run<L, true>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
+                              sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
+                              part_denc, snk);
+    else
+        backward_run<L, false>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
+                               sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
+                               part_denc, snk);
 }
-
 
 // ---------------------------------------------------------------- mixstats
 // calc_mix_param (TF:1691-1727) over a block of frames.  Element space E = G*(D+1):

@@ -28,6 +28,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr double COND_MAX = 1.0e4; // expanded-form error ~ 4*eps*cond  (<= ~5e-12)
 constexpr int EM_WAVES = 4;        // waves per emission block
+constexpr int EM_XR = 17;          // frame-tile doubles per lane: 16*DP/64, DP <= 68
 
 // Offsets for the expanded forms: offs[c][DP] = mean of the means of tile c's real
 // Gaussians (0 beyond D); oglob[d] = mean of all means (grid = NT + D blocks).
@@ -148,16 +149,34 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
     double *xw = xl + w * 16 * XS;
     const int tps = Mp > 16 ? Mp / 16 : 1;
     const long long ntf = (F + 15) / 16;
-    for (long long tf = (long long)blockIdx.x * EM_WAVES + w; tf < ntf;
-         tf += (long long)gridDim.x * EM_WAVES) {
+    // the wave's 16 x D frame tile is contiguous in HBM; every lane moves EM_XR of its
+    // doubles.  The NEXT tile is fetched into registers while the current one is
+    // computed and dropped into LDS afterwards.
+    int goff[EM_XR], loff[EM_XR];
+#pragma unroll
+    for (int u = 0; u < EM_XR; u++) {
+        const int k = l + 64 * u, r = k / DP, d = k - r * DP;
+        const bool in = k < 16 * DP;
+        loff[u] = in ? r * XS + d : -1;
+        goff[u] = (in && d < D) ? r * D + d : -1;
+    }
+    double xn[EM_XR];
+    auto fetch = [&](long long tf) {
         const long long f0 = tf * 16;
-        const int nf = (int)((F - f0) < 16 ? (F - f0) : 16);
-        // the wave's 16 x D frame tile: contiguous in HBM, read once
-        for (int k = l; k < 16 * DP; k += WAVE) {
-            int r = k / DP, d = k - r * DP;
-            xw[r * XS + d] = (r < nf && d < D) ? X[(f0 + r) * D + d] : 0.0;
-        }
+        const long long lim = (tf < ntf) ? (F - f0) * D : 0; // doubles left in X from f0
+#pragma unroll
+        for (int u = 0; u < EM_XR; u++)
+            xn[u] = (goff[u] >= 0 && goff[u] < lim) ? X[f0 * D + goff[u]] : 0.0;
+    };
+    const long long tstride = (long long)gridDim.x * EM_WAVES;
+    fetch((long long)blockIdx.x * EM_WAVES + w);
+    for (long long tf = (long long)blockIdx.x * EM_WAVES + w; tf < ntf; tf += tstride) {
+        const long long f0 = tf * 16;
+#pragma unroll
+        for (int u = 0; u < EM_XR; u++)
+            if (loff[u] >= 0) xw[loff[u]] = xn[u];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
+        fetch(tf + tstride);
         const double *xr = xw + j * XS; // A rows: frame l&15
         double run[4] = {0.0, 0.0, 0.0, 0.0};
         for (int ct = 0; ct < tc; ct++) {
@@ -195,18 +214,21 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
             }
             double v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = exp(acc[r]) * wkj;
+            for (int r = 0; r < 4; r++) v[r] = exp_emis(acc[r]) * wkj;
             if (Mp <= 16) {
                 const int st = gp / Mp;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    double s = v[r];
-                    for (int o = 1; o < Mp; o <<= 1) s += __shfl_xor(s, o, 16);
+                    const double s = segment_sum(v[r], Mp);
                     const long long fr = f0 + kq + 4 * r;
                     if (fr < F) {
                         if ((j & (Mp - 1)) == 0 && st < N) b[fr * N + st] = s;
-                        // gauss[i][j] /= b_i, 0 when b_i == 0 (TF:1773-1778)
-                        if (post && gm >= 0) post[fr * G + gm] = s != 0.0 ? v[r] / s : 0.0;
+                        // gauss[i][j] /= b_i, 0 when b_i == 0 (TF:1773-1778); a reciprocal
+                        // for normal b_i, the true quotient when b_i is tiny
+                        if (post && gm >= 0) {
+                            const bool nrm = s >= 1.0e-290 && s <= 1.0e290;
+                            post[fr * G + gm] = nrm ? v[r] * recip_scale(s) : (s != 0.0 ? v[r] / s : 0.0);
+                        }
                     }
                 }
             } else {
@@ -223,8 +245,7 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                 if (tin == tps - 1) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        double s = run[r];
-                        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 16);
+                        const double s = segment_sum(run[r], 16);
                         const long long fr = f0 + kq + 4 * r;
                         if (fr < F && st < N) {
                             if (j == 0) b[fr * N + st] = s;
@@ -257,6 +278,7 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
 // a block fold their tiles through LDS in wave order and the block writes ONE partial;
 // k_sum_partials adds the partials in block order (bitwise reproducible).
 constexpr int MSM_WAVES = 4;
+constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
 template <int CT, int NE>
 __global__ void __launch_bounds__(MSM_WAVES *WAVE, 1)
@@ -297,34 +319,38 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
     const long long steps = (F + 3) / 4;
     const long long s0 = steps * wi / nwaves, s1 = steps * (wi + 1) / nwaves;
 
-    double wv[CT], xv[NE], wn[CT], xn[NE];
+    // operands are fetched MSM_PD k-steps ahead (a ring of register stages, statically
+    // indexed): with one wave per SIMD nothing else hides the HBM latency
+    double wq[MSM_PD][CT], xq[MSM_PD][NE];
     auto load = [&](long long st, double *wo, double *xo) {
         const long long t = st * 4 + kq;
-        const bool ok = t < F;
+        const bool ok = st < s1 && t < F;
 #pragma unroll
         for (int c = 0; c < CT; c++)
             wo[c] = (ok && gmA[c] >= 0) ? gamma[t * N + stA[c]] * post[t * G + gmA[c]] : 0.0;
 #pragma unroll
         for (int n = 0; n < NE; n++) xo[n] = (ok && kind[n] < 2) ? X[t * D + dn[n]] : 0.0;
     };
-    if (s0 < s1) load(s0, wv, xv);
-    for (long long st = s0; st < s1; st++) {
-        if (st + 1 < s1) load(st + 1, wn, xn);
-        double ft[NE];
 #pragma unroll
-        for (int n = 0; n < NE; n++) {
-            const double xo = xv[n] - on[n];
-            ft[n] = kind[n] == 0 ? xo : (kind[n] == 1 ? xo * xo : (kind[n] == 2 ? 1.0 : 0.0));
+    for (int u = 0; u < MSM_PD; u++) load(s0 + u, wq[u], xq[u]);
+    for (long long st = s0; st < s1; st += MSM_PD) {
+#pragma unroll
+        for (int u = 0; u < MSM_PD; u++) {
+            if (st + u < s1) {
+                double ft[NE];
+#pragma unroll
+                for (int n = 0; n < NE; n++) {
+                    const double xo = xq[u][n] - on[n];
+                    ft[n] = kind[n] == 0 ? xo : (kind[n] == 1 ? xo * xo : (kind[n] == 2 ? 1.0 : 0.0));
+                }
+#pragma unroll
+                for (int c = 0; c < CT; c++)
+#pragma unroll
+                    for (int n = 0; n < NE; n++)
+                        acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq[u][c], ft[n], acc[c][n], 0, 0, 0);
+            }
+            load(st + u + MSM_PD, wq[u], xq[u]);
         }
-#pragma unroll
-        for (int c = 0; c < CT; c++)
-#pragma unroll
-            for (int n = 0; n < NE; n++)
-                acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], ft[n], acc[c][n], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < CT; c++) wv[c] = wn[c];
-#pragma unroll
-        for (int n = 0; n < NE; n++) xv[n] = xn[n];
     }
     // fold the block's waves in wave order, then write the block's partial
     for (int ww = 0; ww < MSM_WAVES; ww++) {
