@@ -378,13 +378,15 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
         m->tps = Mp > 16 ? Mp / 16 : 1;
         m->NT = (int)(((size_t)N * Mp + 15) / 16);
         m->DP = (D + 1 + 3) / 4 * 4;
-        const size_t per_tile = (size_t)(m->DP / 2) * 64 * 8 + (size_t)m->DP * 8;
-        int tcmax = (int)((56 * 1024) / per_tile);
+        const size_t per_tile = (size_t)(m->DP / 2) * 64 * 8;
+        const size_t slabs = (size_t)EM_WAVES * 16 * (2 * m->DP + 1) * 8;
+        int tcmax = (int)((150 * 1024 - slabs) / per_tile);
+        if (tcmax > 6) tcmax = 6;
         int TC = tcmax / m->tps * m->tps;
         if (TC > m->NT) TC = m->NT;
         m->TC = TC;
-        m->em_lds = (size_t)TC * per_tile + (size_t)EM_WAVES * 16 * (m->DP + 1) * 8;
-        m->mfma_ok = TC >= m->tps && TC > 0 && m->em_lds <= 150 * 1024 && 16 * m->DP <= 64 * EM_XR;
+        m->em_lds = (size_t)TC * per_tile + slabs;
+        m->mfma_ok = TC >= m->tps && TC > 0 && m->em_lds <= 150 * 1024 && 16 * m->D <= 64 * EM_XR;
         if (m->mfma_ok) {
             size_t nw = (size_t)m->NT * (m->DP / 2) * 64;
             if ((rc = dev_alloc(&m->Wm, nw)) || (rc = dev_alloc(&m->offs, (size_t)m->NT * m->DP)) ||
@@ -698,15 +700,13 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const long long ntf = (c->F + 15) / 16;
         const int chunks = (m->NT + m->TC - 1) / m->TC;
         long long gx = (ntf + EM_WAVES - 1) / EM_WAVES;
-        long long cap = (2LL * ctx->cus + chunks - 1) / chunks;
-        if (cap < 32) cap = 32;
-        if (gx > cap) gx = cap;
+        if (gx > ctx->cus) gx = ctx->cus; // one 8-wave block per CU, chunks in grid.y
         {
             kscope ks(ctx, GHMM_K_EMISSION);
             hipLaunchKernelGGL(k_emission_mfma, dim3((unsigned)gx, (unsigned)chunks),
                                dim3(EM_WAVES * WAVE), m->em_lds, ctx->stream, m->N, m->M, m->Mp, m->D,
-                               m->DP, m->NT, m->TC, c->F, c->X, m->Wm, m->offs, m->wkp, m->gmap,
-                               m->condp, m->mean, m->inv_var, ctx->b, post);
+                               m->DP, m->NT, m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap,
+                               m->condg, m->mean, m->inv_var, ctx->b, post);
         }
         ctx->b_is_log = false;
         return launch_ok("k_emission_mfma");

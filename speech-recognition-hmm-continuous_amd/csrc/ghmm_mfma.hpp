@@ -27,8 +27,8 @@ namespace ghmm {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr double COND_MAX = 1.0e4; // expanded-form error ~ 4*eps*cond  (<= ~5e-12)
-constexpr int EM_WAVES = 4;        // waves per emission block
-constexpr int EM_XR = 17;          // frame-tile doubles per lane: 16*DP/64, DP <= 68
+constexpr int EM_WAVES = 8;        // waves per emission block (one block per CU)
+constexpr int EM_XR = 16;          // frame-tile doubles per lane: 16*D/64, D <= 64
 
 // Offsets for the expanded forms: offs[c][DP] = mean of the means of tile c's real
 // Gaussians (0 beyond D); oglob[d] = mean of all means (grid = NT + D blocks).
@@ -69,8 +69,9 @@ k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__r
 // One thread per padded Gaussian gp = 16*c + j (state gp / Mp, mixture gp % Mp).
 //   Wm[c][s][lane]  B fragments in lane order: row kk = 4s + (lane>>4), col lane&15
 //                   rows 0..DP-1 multiply [x'_0..x'_{D-1}, 1, 0..], rows DP.. multiply x'^2
-//   wkp[gp], gmap[gp] (-1 = padding); condp / condg = sum_d inv_d mu'_d^2 with the tile
-//   offset / the global offset (the cancellation measure of the two expanded forms)
+//   wkp[gp], gmap[gp] (-1 = padding); condg = sum_d inv_d mu'_d^2 with mu' = mu - oglob,
+//   the cancellation measure of the expanded forms (condp: the same around the tile's
+//   own offset, kept for diagnostics)
 __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
                                const double *__restrict__ mean, const double *__restrict__ inv_var,
                                const double *__restrict__ wk, const double *__restrict__ offs,
@@ -92,17 +93,17 @@ __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
         double bc = 0.0, ac = 0.0;
         if (real && d < D) {
             const double mraw = mean[(size_t)g * D + d], iv = inv_var[(size_t)g * D + d];
-            const double mu = mraw - offs[(size_t)c * DP + d], mg = mraw - oglob[d];
+            const double mu = mraw - oglob[d], mt = mraw - offs[(size_t)c * DP + d];
             bc = mu * iv;
             ac = -0.5 * iv;
-            c0 += mu * mu * iv;
-            cg += mg * mg * iv;
+            cg += mu * mu * iv;
+            c0 += mt * mt * iv;
         }
         if (d != D) Wc[(d >> 2) * 64 + (d & 3) * 16 + j] = bc;
         const int k2 = DP + d;
         Wc[(k2 >> 2) * 64 + (k2 & 3) * 16 + j] = ac;
     }
-    Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * c0 : 0.0; // multiplies the constant 1
+    Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0; // multiplies the constant 1
     condp[gp] = real ? c0 : 0.0;
     condg[gp] = real ? cg : 0.0;
 }
@@ -123,79 +124,89 @@ __global__ void k_any_flag(int n, const double *__restrict__ condg, int *__restr
 
 // calc_symbol_probab + calc_gaus (TF:1749-1841) for 16 frames x TC Gaussian tiles per
 // wave iteration, linear domain (the reference's: exp(q) * c / (norm), summed over the
-// state's mixtures, posteriors = share of the sum).  blockIdx.y picks the chunk of TC
-// tiles whose B fragments are resident in LDS; blocks stride over frame tiles.
+// state's mixtures, posteriors = share of the sum).  One block of EM_WAVES waves per
+// CU; blockIdx.y picks the chunk of TC tiles whose B fragments the block keeps in LDS;
+// waves stride over frame tiles.  Per frame tile a wave builds the extended frames
+// Fext[16][2*DP] = [x', 1, 0.., x'^2, 0..] (x' = x - oglob) in its own LDS slab ONCE; every
+// MFMA then takes both operands from LDS with no vector-ALU work in between.
 //   Mp <= 16: Mp is a power of two, a state's mixtures sit in Mp adjacent lanes;
 //   Mp  > 16: Mp is a multiple of 16, a state spans Mp/16 consecutive tiles of the chunk.
 __global__ void __launch_bounds__(EM_WAVES *WAVE, 2)
 k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F,
                 const double *__restrict__ X, const double *__restrict__ Wm,
-                const double *__restrict__ offs, const double *__restrict__ wkp,
-                const int *__restrict__ gmap, const double *__restrict__ condp,
+                const double *__restrict__ oglob, const double *__restrict__ wkp,
+                const int *__restrict__ gmap, const double *__restrict__ condg,
                 const double *__restrict__ mean, const double *__restrict__ inv_var,
                 double *__restrict__ b, double *__restrict__ post)
 {
     extern __shared__ double lds[];
-    const int KS = DP / 2, Q = DP / 4, XS = DP + 1, G = N * M;
+    const int KS = DP / 2, XS = 2 * DP + 1, G = N * M;
     double *Wl = lds;                                // [TC][KS][64]
-    double *ol = Wl + (size_t)TC * KS * 64;          // [TC][DP]
-    double *xl = ol + (size_t)TC * DP;               // [EM_WAVES][16][XS]
+    double *xl = Wl + (size_t)TC * KS * 64;          // [EM_WAVES][16][XS]
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int c0 = blockIdx.y * TC;
     const int tc = (NT - c0) < TC ? (NT - c0) : TC;
     for (int k = tid; k < tc * KS * 64; k += EM_WAVES * WAVE) Wl[k] = Wm[(size_t)c0 * KS * 64 + k];
-    for (int k = tid; k < tc * DP; k += EM_WAVES * WAVE) ol[k] = offs[(size_t)c0 * DP + k];
     __syncthreads();
     double *xw = xl + w * 16 * XS;
     const int tps = Mp > 16 ? Mp / 16 : 1;
     const long long ntf = (F + 15) / 16;
-    // the wave's 16 x D frame tile is contiguous in HBM; every lane moves EM_XR of its
-    // doubles.  The NEXT tile is fetched into registers while the current one is
-    // computed and dropped into LDS afterwards.
-    int goff[EM_XR], loff[EM_XR];
+    const long long FD = F * D;
+    // the wave's 16 x D frame tile is contiguous in HBM; lane l moves elements l + 64u.
+    // The NEXT tile is fetched into registers while the current one is computed.
+    int loff[EM_XR], roff[EM_XR];
+    double oo[EM_XR];
 #pragma unroll
     for (int u = 0; u < EM_XR; u++) {
-        const int k = l + 64 * u, r = k / DP, d = k - r * DP;
-        const bool in = k < 16 * DP;
+        const int k = l + 64 * u, r = k / D, d = k - r * D;
+        const bool in = k < 16 * D;
         loff[u] = in ? r * XS + d : -1;
-        goff[u] = (in && d < D) ? r * D + d : -1;
+        roff[u] = in ? k : 0;
+        oo[u] = in ? oglob[d] : 0.0;
     }
     double xn[EM_XR];
     auto fetch = [&](long long tf) {
-        const long long f0 = tf * 16;
-        const long long lim = (tf < ntf) ? (F - f0) * D : 0; // doubles left in X from f0
+        const long long base = tf * 16 * D;
 #pragma unroll
-        for (int u = 0; u < EM_XR; u++)
-            xn[u] = (goff[u] >= 0 && goff[u] < lim) ? X[f0 * D + goff[u]] : 0.0;
+        for (int u = 0; u < EM_XR; u++) {
+            long long q = base + roff[u];
+            q = q < FD ? q : FD - 1; // clamped, never predicated (keeps vmcnt countable)
+            xn[u] = X[q];
+        }
     };
+    // columns that never change: the constant 1 and the zero padding of both halves
+    for (int k = l; k < 16 * (2 * DP - 2 * D); k += WAVE) {
+        const int r = k / (2 * DP - 2 * D), e = k - r * (2 * DP - 2 * D);
+        const int col = e < DP - D ? D + e : DP + D + (e - (DP - D));
+        xw[r * XS + col] = (col == D) ? 1.0 : 0.0;
+    }
     const long long tstride = (long long)gridDim.x * EM_WAVES;
-    fetch((long long)blockIdx.x * EM_WAVES + w);
-    for (long long tf = (long long)blockIdx.x * EM_WAVES + w; tf < ntf; tf += tstride) {
+    long long tf = (long long)blockIdx.x * EM_WAVES + w;
+    fetch(tf < ntf ? tf : 0);
+    for (; tf < ntf; tf += tstride) {
         const long long f0 = tf * 16;
 #pragma unroll
         for (int u = 0; u < EM_XR; u++)
-            if (loff[u] >= 0) xw[loff[u]] = xn[u];
+            if (loff[u] >= 0) {
+                const double xo = xn[u] - oo[u];
+                xw[loff[u]] = xo;
+                xw[loff[u] + DP] = xo * xo;
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
-        fetch(tf + tstride);
-        const double *xr = xw + j * XS; // A rows: frame l&15
+        fetch(tf + tstride < ntf ? tf + tstride : tf);
+        const double *xr = xw + j * XS + kq; // A operand: frame l&15, k = 4s + (l>>4)
         double run[4] = {0.0, 0.0, 0.0, 0.0};
         for (int ct = 0; ct < tc; ct++) {
             const int gp = (c0 + ct) * 16 + j;
             const double wkj = wkp[gp];
             const int gm = gmap[gp];
-            const bool flagged = __any(condp[gp] > COND_MAX);
+            const bool flagged = __any(condg[gp] > COND_MAX);
             v4d acc = {0.0, 0.0, 0.0, 0.0};
             if (!flagged) {
                 const double *Wt = Wl + (size_t)ct * KS * 64 + l;
-                const double *ot = ol + ct * DP;
-                for (int s = 0; s < Q; s++) {
-                    const int d = 4 * s + kq;
-                    const double xo = xr[d] - ot[d];
-                    const double a1 = d < D ? xo : (d == D ? 1.0 : 0.0);
-                    const double a2 = d < D ? xo * xo : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Wt[s * 64], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Wt[(Q + s) * 64], acc, 0, 0, 0);
-                }
+#pragma unroll 4
+                for (int s = 0; s < KS; s++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[4 * s], Wt[s * 64], acc, 0, 0, 0);
             } else {
                 // ill-conditioned tile: the reference's own form, TF:1829-1832
 #pragma unroll
@@ -205,7 +216,7 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                         const double *xf = xw + (kq + 4 * r) * XS;
                         const double *mu = mean + (size_t)gm * D, *iv = inv_var + (size_t)gm * D;
                         for (int d = 0; d < D; d++) {
-                            double dif = xf[d] - mu[d];
+                            double dif = xf[d] - (mu[d] - oglob[d]);
                             q += dif * iv[d] * dif;
                         }
                     }
@@ -265,7 +276,6 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
     }
 }
 
-
 // ---------------------------------------------------------------- mixstats
 // calc_mix_param (TF:1691-1727) as a matrix product over the time axis:
 //     S[g][e] = sum_t w_t(g) * Fext_t[e],  w_t(g) = gamma_t(state(g)) * post_t(g) (TF:1706-1711)
@@ -322,14 +332,24 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
     // operands are fetched MSM_PD k-steps ahead (a ring of register stages, statically
     // indexed): with one wave per SIMD nothing else hides the HBM latency
     double wq[MSM_PD][CT], xq[MSM_PD][NE];
+    // every load is unconditional (addresses clamped into the arrays, results masked):
+    // a load under a branch makes hipcc wait vmcnt(0) and the prefetch ring collapses
+    int gmC[CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) gmC[c] = gmA[c] >= 0 ? gmA[c] : 0;
+#pragma unroll
+    for (int c = 0; c < CT; c++) stA[c] = stA[c] < N ? stA[c] : 0;
     auto load = [&](long long st, double *wo, double *xo) {
-        const long long t = st * 4 + kq;
+        long long t = st * 4 + kq;
         const bool ok = st < s1 && t < F;
+        t = t < F ? t : F - 1;
 #pragma unroll
-        for (int c = 0; c < CT; c++)
-            wo[c] = (ok && gmA[c] >= 0) ? gamma[t * N + stA[c]] * post[t * G + gmA[c]] : 0.0;
+        for (int c = 0; c < CT; c++) {
+            const double w = gamma[t * N + stA[c]] * post[t * G + gmC[c]];
+            wo[c] = (ok && gmA[c] >= 0) ? w : 0.0;
+        }
 #pragma unroll
-        for (int n = 0; n < NE; n++) xo[n] = (ok && kind[n] < 2) ? X[t * D + dn[n]] : 0.0;
+        for (int n = 0; n < NE; n++) xo[n] = X[t * D + dn[n]];
     };
 #pragma unroll
     for (int u = 0; u < MSM_PD; u++) load(s0 + u, wq[u], xq[u]);
