@@ -308,34 +308,35 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     const int da = act ? N : 0;
     double *pcs = (i == 0) ? su : (i == 1 ? si : sink);
     const int dc = (i < 2) ? 1 : 0;
-    const double *pb = act ? bu + i : sink; // b cursor (sink holds finite junk for idle lanes)
+    const double *pb = act ? bu + i : sink; // frame 0 of b (idle lanes: the sink, stride 0)
     const int db = act ? N : 0;
+    // b of frame f, clamped into the utterance: loads are never predicated (a load under
+    // a branch makes hipcc wait vmcnt(0) at every step)
+    auto bget = [&](int f) { return pb[(size_t)(f < T ? f : T - 1) * db]; };
 
     // t = 0
     {
-        const double a0 = ((i == 0) ? 1.0 : 0.0) * (act ? *pb : 0.0);
+        const double a0 = ((i == 0) ? 1.0 : 0.0) * (act ? bget(0) : 0.0);
         const double s = group_sum<L>(a0);
         const double c = recip_select(s);
         st.a = a0 * c;
         *pa = st.a;
         *pcs = (i == 0) ? c : s;
-        pa += da; pcs += dc; pb += db;
+        pa += da; pcs += dc;
     }
     double bq[PF];
     int t = 1;
 #pragma unroll
-    for (int k = 0; k < PF; k++) bq[k] = (t + k < T) ? pb[(size_t)k * db] : 0.0;
+    for (int k = 0; k < PF; k++) bq[k] = bget(t + k);
     for (; t + PF <= T; t += PF) {
         double bn[PF];
-        const double *pn = pb + (size_t)PF * db;
 #pragma unroll
-        for (int k = 0; k < PF; k++) bn[k] = (t + PF + k < T) ? pn[(size_t)k * db] : 0.0;
+        for (int k = 0; k < PF; k++) bn[k] = bget(t + PF + k);
 #pragma unroll
         for (int k = 0; k < PF; k++) {
             st.step(bq[k], pa, pcs, i);
             pa += da; pcs += dc;
         }
-        pb = pn;
 #pragma unroll
         for (int k = 0; k < PF; k++) bq[k] = bn[k];
     }
@@ -461,16 +462,16 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
         st.xi[o] = 0.0;
     }
     const int dn = act ? N : 0;
-    // cursors at t = T-1 (lanes without a state read/write the sink, stride 0)
-    const double *pa = act ? au + (size_t)(T - 1) * N + i : sink;
-    const double *pb = act ? bu + (size_t)(T - 1) * N + i : sink;
+    // frame-indexed readers, clamped into the utterance (never predicated); lanes without
+    // a state read / write the sink with stride 0
+    const double *pa0 = act ? au + i : sink, *pb0 = act ? bu + i : sink;
+    auto clampf = [&](int f) { return (size_t)(f < 0 ? 0 : f); };
     double *pbe = act ? beu + (size_t)(T - 1) * N + i : sink;
     double *pg = act ? gu + (size_t)(T - 1) * N + i : sink;
-    const double *pc = su + (T - 1), *ps = si + (T - 1);
     {
-        const double cT = *pc;
+        const double cT = su[T - 1];
         st.be = (i == N - 1) ? 1.0 * cT : 0.0;
-        const double g = (act ? *pa : 0.0) * st.be * *ps;
+        const double g = (act ? pa0[(size_t)(T - 1) * dn] : 0.0) * st.be * si[T - 1];
         *pbe = st.be;
         *pg = g;
         st.denc += g;
@@ -480,23 +481,22 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
     int t = T - 2;
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        const bool ok = t - k >= 0;
-        qb[k] = ok ? *(pb - (size_t)k * dn) : 0.0;
-        qa[k] = ok ? *(pa - (size_t)(k + 1) * dn) : 0.0;
-        qc[k] = ok ? *(pc - (k + 1)) : 1.0;
-        qs[k] = ok ? *(ps - (k + 1)) : 1.0;
+        const size_t f = clampf(t - k);
+        qb[k] = pb0[(f + 1 < (size_t)T ? f + 1 : (size_t)T - 1) * dn];
+        qa[k] = pa0[f * dn];
+        qc[k] = su[f];
+        qs[k] = si[f];
     }
     pbe -= dn; pg -= dn;
     for (; t - PF + 1 >= 0; t -= PF) {
         double nb[PF], na[PF], nc[PF], ns[PF];
-        pb -= (size_t)PF * dn; pa -= (size_t)PF * dn; pc -= PF; ps -= PF;
 #pragma unroll
         for (int k = 0; k < PF; k++) {
-            const bool ok = t - PF - k >= 0;
-            nb[k] = ok ? *(pb - (size_t)k * dn) : 0.0;
-            na[k] = ok ? *(pa - (size_t)(k + 1) * dn) : 0.0;
-            nc[k] = ok ? *(pc - (k + 1)) : 1.0;
-            ns[k] = ok ? *(ps - (k + 1)) : 1.0;
+            const size_t f = clampf(t - PF - k);
+            nb[k] = pb0[(f + 1 < (size_t)T ? f + 1 : (size_t)T - 1) * dn];
+            na[k] = pa0[f * dn];
+            nc[k] = su[f];
+            ns[k] = si[f];
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {

@@ -339,15 +339,17 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
     for (int c = 0; c < CT; c++) gmC[c] = gmA[c] >= 0 ? gmA[c] : 0;
 #pragma unroll
     for (int c = 0; c < CT; c++) stA[c] = stA[c] < N ? stA[c] : 0;
+    double mk[CT]; // 1 for a real Gaussian, 0 for padding: masks by multiplication, so
+                   // that hipcc cannot sink the loads under a branch
+#pragma unroll
+    for (int c = 0; c < CT; c++) mk[c] = gmA[c] >= 0 ? 1.0 : 0.0;
     auto load = [&](long long st, double *wo, double *xo) {
         long long t = st * 4 + kq;
-        const bool ok = st < s1 && t < F;
+        const double okf = (st < s1 && t < F) ? 1.0 : 0.0;
         t = t < F ? t : F - 1;
 #pragma unroll
-        for (int c = 0; c < CT; c++) {
-            const double w = gamma[t * N + stA[c]] * post[t * G + gmC[c]];
-            wo[c] = (ok && gmA[c] >= 0) ? w : 0.0;
-        }
+        for (int c = 0; c < CT; c++)
+            wo[c] = gamma[t * N + stA[c]] * post[t * G + gmC[c]] * (mk[c] * okf);
 #pragma unroll
         for (int n = 0; n < NE; n++) xo[n] = X[t * D + dn[n]];
     };
