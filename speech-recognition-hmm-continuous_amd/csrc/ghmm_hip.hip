@@ -324,29 +324,29 @@ extern "C" int ghmm_ctx_kernel_time_reset(ghmm_ctx *ctx)
 
 // ------------------------------------------------------------------- model
 
-static int model_prepare(ghmm_ctx *ctx, ghmm_model *m)
+static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
 {
     // pow(2*pi, D/2): the reference's aux1 (TF:1821-1823), evaluated by the host libm
     const double norm2pi = pow(2.0 * M_PI, m->D / 2.0);
     const int G = m->N * m->M;
-    int work = G > m->N * m->N ? G : m->N * m->N;
-    int blocks = (work + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    {
+    int rc;
+    if (base) { // after ghmm_model_set; k_mstep derives the same constants itself
+        int work = G > m->N * m->N ? G : m->N * m->N;
+        int blocks = (work + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
         kscope ks(ctx, GHMM_K_PREPARE);
         hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(256), 0, ctx->stream, m->N, m->M, m->A,
                            m->c, m->det, norm2pi, m->wk, m->logwk, m->logA);
     }
-    int rc = launch_ok("k_prepare");
-    if (rc || !m->mfma_ok) return rc;
+    if ((rc = launch_ok("k_prepare")) || !m->mfma_ok) return rc;
     {
         kscope ks(ctx, GHMM_K_PREPARE);
         hipLaunchKernelGGL(k_prepare_offsets, dim3((unsigned)(m->NT + m->D)), dim3(64), 0, ctx->stream,
-                           m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob);
+                           m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob,
+                           m->anyflag);
         hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)((m->NT * 16 + 63) / 64)), dim3(64), 0,
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
-                           m->wk, m->offs, m->oglob, m->Wm, m->wkp, m->gmap, m->condp, m->condg);
-        hipLaunchKernelGGL(k_any_flag, dim3(1), dim3(256), 0, ctx->stream, m->NT * 16, m->condg,
+                           m->wk, m->offs, m->oglob, m->Wm, m->wkp, m->gmap, m->condp, m->condg,
                            m->anyflag);
     }
     return launch_ok("k_prepare_mfma");
@@ -437,7 +437,7 @@ extern "C" int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, con
     HIP_TRY(hipMemcpyAsync(m->det, det, G * 8, hipMemcpyHostToDevice, ctx->stream));
     // pageable host memory: the copies above have consumed the buffers on return
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return model_prepare(ctx, m);
+    return model_prepare(ctx, m, true);
 }
 
 extern "C" int ghmm_model_get(ghmm_ctx *ctx, ghmm_model *m, double *A, double *c, double *mean,
@@ -836,8 +836,6 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     const int NB = (int)((E + MS_THREADS * MS_EPT - 1) / (MS_THREADS * MS_EPT));
     const bool mfma = m->mfma_ok && m->CT > 0 && ctx->kernels != 1;
     int rc;
-    double *num_c = s->v + (size_t)N * N + 2 * (size_t)N;
-    double *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
     // frame-block partials: enough blocks to fill the chip a few times over, few
     // enough that the partial sums stay small next to the frame data
     long long P = ctx->partials > 0 ? ctx->partials : (2LL * ctx->cus + NB - 1) / NB;
@@ -874,7 +872,6 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         if (Pm < 1) Pm = 1;
         nsum = (size_t)m->NT * 16 * m->NE * 16;
         if ((rc = dev_grow(&ctx->part_m, &ctx->cap_pm, (size_t)Pm * nsum))) return rc;
-        if ((rc = dev_grow(&ctx->sums, &ctx->cap_sums, nsum))) return rc;
         {
             kscope ks(ctx, GHMM_K_MIXSTATS);
             switch (m->NE) {
@@ -899,25 +896,23 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
                            ctx->part_mu, ctx->part_var, only_if);
         if ((rc = launch_ok("k_mixstats"))) return rc;
     }
-    const size_t off_ll = s->n - 2;
     {
+        reduce_args ra;
+        ra.N = N; ra.M = M; ra.D = D; ra.U = c->U; ra.delta = (int)ctx->delta;
+        ra.P1 = (int)P; ra.part_mu = ctx->part_mu; ra.part_var = ctx->part_var;
+        ra.Pm = (mfma && c->F > 0) ? Pm : 0;
+        ra.NT = m->NT; ra.DP = m->DP; ra.ES = m->NE * 16;
+        ra.part_m = ctx->part_m; ra.condg = m->condg; ra.oglob = m->oglob; ra.mean = m->mean;
+        ra.gmap = m->gmap; ra.cond_max = COND_MAX;
+        ra.part_xi = ctx->part_xi; ra.part_dena = ctx->part_dena; ra.part_denc = ctx->part_denc;
+        ra.loglik = ctx->loglik; ra.stats = s->v;
+        if (mfma && c->F == 0) ra.P1 = 0; // nothing accumulated: every sum is empty
+        const int NGb = ra.Pm > 0 ? m->NT * 16 : G;
         kscope ks(ctx, GHMM_K_REDUCE);
-        hipLaunchKernelGGL(k_reduce_utt, dim3((unsigned)(N * N + 2 * N + 1)), dim3(RD_THREADS), 0,
-                           ctx->stream, N, c->U, (int)ctx->delta, ctx->part_xi, ctx->part_dena,
-                           ctx->part_denc, ctx->loglik, s->v, off_ll);
-        hipLaunchKernelGGL(k_reduce_mix, dim3((unsigned)((E + RD_THREADS - 1) / RD_THREADS)),
-                           dim3(RD_THREADS), 0, ctx->stream, N, M, D, (int)P, ctx->part_mu,
-                           ctx->part_var, num_c, num_mu, num_var, only_if);
-        if (mfma) {
-            hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((nsum + 63) / 64)), dim3(256), 0,
-                               ctx->stream, (long long)nsum, c->F > 0 ? Pm : 0, ctx->part_m, ctx->sums);
-            const long long nfin = (long long)m->NT * 16 * D1;
-            hipLaunchKernelGGL(k_finish_mix, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0,
-                               ctx->stream, N, M, D, m->DP, m->NT, m->NE * 16, ctx->sums, m->gmap,
-                               m->condg, m->oglob, m->mean, num_c, num_mu, num_var);
-        }
+        hipLaunchKernelGGL(k_reduce_all, dim3((unsigned)(NGb + N * N + 2 * N + 1)), dim3(RD_THREADS), 0,
+                           ctx->stream, ra);
     }
-    return launch_ok("k_reduce");
+    return launch_ok("k_reduce_all");
 }
 
 static int check_stats(const ghmm_model *m, const ghmm_stats *s)
@@ -992,11 +987,14 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
     if ((rc = check_stats(m, s))) return rc;
     {
         kscope ks(ctx, GHMM_K_MSTEP);
-        hipLaunchKernelGGL(k_mstep, dim3(1), dim3(256), 0, ctx->stream, m->N, m->M, m->D, s->v, m->A,
-                           m->c, m->mean, m->inv_var, m->det);
+        size_t md = (size_t)m->M * m->D;
+        int lds_doubles = md * 8 <= 60 * 1024 ? (int)md : 0;
+        hipLaunchKernelGGL(k_mstep, dim3((unsigned)m->N), dim3(MS2_THREADS), (size_t)lds_doubles * 8,
+                           ctx->stream, m->N, m->M, m->D, s->v, pow(2.0 * M_PI, m->D / 2.0), m->A, m->c,
+                           m->mean, m->inv_var, m->det, m->wk, m->logwk, m->logA, lds_doubles);
     }
     if ((rc = launch_ok("k_mstep"))) return rc;
-    return model_prepare(ctx, m);
+    return model_prepare(ctx, m, false);
 }
 
 extern "C" int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *loglik_host)

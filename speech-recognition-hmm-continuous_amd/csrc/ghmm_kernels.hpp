@@ -646,10 +646,17 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
 
 // ------------------------------------------------------------------- reduce
 // Ordered sums of all partials into the flat statistics vector (layout:
-// include/ghmm.h).  One block per output quantity group; every sum is taken in a
-// fixed order (thread-strided ascending, then a fixed LDS tree), so the result
-// does not depend on scheduling.
-constexpr int RD_THREADS = 256;
+// include/ghmm.h) in ONE launch.  Every sum is taken in a fixed order (thread-strided
+// ascending, then a fixed LDS tree), so the result does not depend on scheduling.
+//   blocks [0, NG)        one per Gaussian: the frame-block partials of k_mixstats (vector
+//                         ALU tier, [P1][G*(D+1)]) or of k_mixstats_mfma (matrix-core tier,
+//                         [Pm][NT*16][ES] expanded sums S, converted here:
+//                           num_c = S[D], num_mu_d = S_d + o_d num_c,
+//                           num_var_d = S_{DP+d} - 2 mu'_d S_d + mu'_d^2 num_c, mu' = mu - o);
+//                         an ill-conditioned Gaussian (cond > cond_max) takes the vector-ALU
+//                         sums on the matrix-core tier too
+//   blocks [NG, NG+NU)    per-utterance partials of k_backward: num_a, den_a, den_c, loglik
+constexpr int RD_THREADS = 1024; // 128 feature lanes x 8 partial slices
 
 __device__ inline double block_sum_fixed(double v, double *sh)
 {
@@ -664,65 +671,116 @@ __device__ inline double block_sum_fixed(double v, double *sh)
     return r;
 }
 
-// grid.x = N*N (num_a) + N (den_a) + N (den_c) + 1 (loglik, n_utt)
-__global__ void __launch_bounds__(RD_THREADS)
-k_reduce_utt(int N, int U, int delta, const double *__restrict__ part_xi,
-             const double *__restrict__ part_dena, const double *__restrict__ part_denc,
-             const double *__restrict__ loglik, double *__restrict__ stats, size_t off_loglik)
+struct reduce_args {
+    int N, M, D, U, delta;
+    // vector-ALU partials
+    int P1;
+    const double *part_mu, *part_var;
+    // matrix-core partials (Pm == 0: tier not in use)
+    int Pm, NT, DP, ES;
+    const double *part_m, *condg, *oglob, *mean;
+    const int *gmap;
+    double cond_max;
+    // utterance partials
+    const double *part_xi, *part_dena, *part_denc, *loglik;
+    double *stats;
+};
+
+__global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
 {
     __shared__ double sh[RD_THREADS];
-    const int q = blockIdx.x;
+    __shared__ double sh2[RD_THREADS];
+    const int N = a.N, M = a.M, D = a.D, G = N * M, D1 = D + 1;
+    const int NG = a.Pm > 0 ? a.NT * 16 : G;
+    const int tid = threadIdx.x;
+    double *num_a = a.stats, *den_a = num_a + (size_t)N * N, *den_c = den_a + N;
+    double *num_c = den_c + N, *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
+    if ((int)blockIdx.x < NG) {
+        const int gp = blockIdx.x;
+        const int g = a.Pm > 0 ? a.gmap[gp] : gp;
+        if (g < 0) return;
+        constexpr int SL = RD_THREADS / 128;
+        const int e = tid & 127, half = tid >> 7;
+        if (a.Pm > 0 && !(a.condg[gp] > a.cond_max)) {
+            double v = 0.0;
+            if (e < a.ES)
+                for (int p = half; p < a.Pm; p += SL)
+                    v += a.part_m[((size_t)p * a.NT * 16 + gp) * a.ES + e];
+            sh[tid] = v;
+            __syncthreads();
+            if (tid < 128) {
+                double t = sh[tid];
+                for (int q = 1; q < SL; q++) t += sh[q * 128 + tid];
+                sh[tid] = t;
+            }
+            __syncthreads();
+            if (tid < D1) {
+                const double S0 = sh[D];
+                if (tid == D) {
+                    num_c[g] = S0;
+                } else {
+                    const double o = a.oglob[tid], mu = a.mean[(size_t)g * D + tid] - o;
+                    num_mu[(size_t)g * D + tid] = sh[tid] + o * S0;
+                    num_var[(size_t)g * D + tid] = (sh[a.DP + tid] - 2.0 * mu * sh[tid]) + mu * mu * S0;
+                }
+            }
+        } else {
+            const long long E = (long long)G * D1;
+            for (int d0 = 0; d0 < D1; d0 += 128) {
+                const int d = d0 + e;
+                double vm = 0.0, vv = 0.0;
+                if (d < D1)
+                    for (int p = half; p < a.P1; p += SL) {
+                        vm += a.part_mu[(size_t)p * E + (size_t)g * D1 + d];
+                        vv += a.part_var[(size_t)p * E + (size_t)g * D1 + d];
+                    }
+                sh[tid] = vm;
+                sh2[tid] = vv;
+                __syncthreads();
+                if (tid < 128 && d < D1) {
+                    double sm = sh[tid], sv = sh2[tid];
+                    for (int q = 1; q < SL; q++) {
+                        sm += sh[q * 128 + tid];
+                        sv += sh2[q * 128 + tid];
+                    }
+                    if (d < D) {
+                        num_mu[(size_t)g * D + d] = sm;
+                        num_var[(size_t)g * D + d] = sv;
+                    } else {
+                        num_c[g] = sm;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    const int q = blockIdx.x - NG, U = a.U;
     double v = 0.0;
     if (q < N * N) {
         int i = q / N, j = q % N, o = j - i;
-        if (o >= 0 && o <= delta)
-            for (int u = threadIdx.x; u < U; u += RD_THREADS)
-                v += part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o];
+        if (o >= 0 && o <= a.delta)
+            for (int u = tid; u < U; u += RD_THREADS)
+                v += a.part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o];
         v = block_sum_fixed(v, sh);
-        if (threadIdx.x == 0) stats[q] = v;
+        if (tid == 0) num_a[q] = v;
     } else if (q < N * N + N) {
         int i = q - N * N;
-        for (int u = threadIdx.x; u < U; u += RD_THREADS) v += part_dena[(size_t)u * N + i];
+        for (int u = tid; u < U; u += RD_THREADS) v += a.part_dena[(size_t)u * N + i];
         v = block_sum_fixed(v, sh);
-        if (threadIdx.x == 0) stats[q] = v;
+        if (tid == 0) den_a[i] = v;
     } else if (q < N * N + 2 * N) {
         int i = q - N * N - N;
-        for (int u = threadIdx.x; u < U; u += RD_THREADS) v += part_denc[(size_t)u * N + i];
+        for (int u = tid; u < U; u += RD_THREADS) v += a.part_denc[(size_t)u * N + i];
         v = block_sum_fixed(v, sh);
-        if (threadIdx.x == 0) stats[q] = v;
+        if (tid == 0) den_c[i] = v;
     } else {
-        for (int u = threadIdx.x; u < U; u += RD_THREADS) v += loglik[u];
+        for (int u = tid; u < U; u += RD_THREADS) v += a.loglik[u];
         v = block_sum_fixed(v, sh);
-        if (threadIdx.x == 0) {
-            stats[off_loglik] = v;
-            stats[off_loglik + 1] = (double)U;
+        if (tid == 0) {
+            num_var[(size_t)G * D] = v;            // loglik
+            num_var[(size_t)G * D + 1] = (double)U; // n_utt
         }
-    }
-}
-
-// one thread per element (g, d in 0..D); sums the P frame-block partials in order
-__global__ void __launch_bounds__(RD_THREADS)
-k_reduce_mix(int N, int M, int D, int P, const double *__restrict__ part_mu,
-             const double *__restrict__ part_var, double *__restrict__ num_c,
-             double *__restrict__ num_mu, double *__restrict__ num_var,
-             const int *__restrict__ only_if)
-{
-    if (only_if && only_if[0] == 0) return;
-    const int G = N * M, D1 = D + 1;
-    const long long E = (long long)G * D1;
-    long long e = (long long)blockIdx.x * RD_THREADS + threadIdx.x;
-    if (e >= E) return;
-    double sm = 0.0, sv = 0.0;
-    for (int p = 0; p < P; p++) {
-        sm += part_mu[(size_t)p * E + e];
-        sv += part_var[(size_t)p * E + e];
-    }
-    int g = (int)(e / D1), d = (int)(e - (long long)g * D1);
-    if (d < D) {
-        num_mu[(size_t)g * D + d] = sm;
-        num_var[(size_t)g * D + d] = sv;
-    } else {
-        num_c[g] = sm;
     }
 }
 
@@ -731,35 +789,39 @@ k_reduce_mix(int N, int M, int D, int P, const double *__restrict__ part_mu,
 // changing_zero_coef (TF:1338-1359), then calc_det (TF:1976) and inv_matrix
 // (TF:2012) as main() chains them (TF:332-346) — including the reference's
 // behaviour for a state whose den_c is 0 (its stored inverse variances go through
-// det/inverse as if they were variances).  Single block: the model is tiny.
-__global__ void __launch_bounds__(256)
-k_mstep(int N, int M, int D, const double *__restrict__ stats, double *__restrict__ A,
-        double *__restrict__ c, double *__restrict__ mean, double *__restrict__ inv_var,
-        double *__restrict__ det)
+// det/inverse as if they were variances) — and the derived constants of k_prepare.
+// One block per state.
+constexpr int MS2_THREADS = 128;
+__global__ void __launch_bounds__(MS2_THREADS)
+k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
+        double *__restrict__ A, double *__restrict__ c, double *__restrict__ mean,
+        double *__restrict__ inv_var, double *__restrict__ det, double *__restrict__ wk,
+        double *__restrict__ logwk, double *__restrict__ logA, int lds_doubles)
 {
-    const int G = N * M;
+    const int G = N * M, i = blockIdx.x, tid = threadIdx.x;
     const double *num_a = stats, *den_a = num_a + (size_t)N * N, *den_c = den_a + N;
     const double *num_c = den_c + N, *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int k = tid; k < N * N; k += nt) {
-        int i = k / N;
-        if (den_a[i] != 0.0) A[k] = num_a[k] / den_a[i];
-    }
-    for (long long k = tid; k < (long long)G * D; k += nt) {
-        int g = (int)(k / D), i = g / M;
-        if (den_c[i] != 0.0) {
-            mean[k] = num_mu[k] / num_c[g];
-            double v = num_var[k] / num_c[g];
-            if (v < FLOOR) v = FLOOR;
-            inv_var[k] = v;
+    for (int j = tid; j < N; j += MS2_THREADS) {
+        double v = A[i * N + j];
+        if (den_a[i] != 0.0) {
+            v = num_a[i * N + j] / den_a[i];
+            A[i * N + j] = v;
         }
+        logA[i * N + j] = v > 0.0 ? log(v) : -INFINITY;
     }
-    for (int g = tid; g < G; g += nt) {
-        int i = g / M;
-        if (den_c[i] != 0.0) c[g] = num_c[g] / den_c[i];
+    if (den_c[i] != 0.0) {
+        for (int k = tid; k < M * D; k += MS2_THREADS) {
+            const int g = i * M + k / D;
+            const size_t q = (size_t)i * M * D + k;
+            mean[q] = num_mu[q] / num_c[g];
+            double v = num_var[q] / num_c[g];
+            if (v < FLOOR) v = FLOOR;
+            inv_var[q] = v;
+        }
+        for (int m = tid; m < M; m += MS2_THREADS) c[i * M + m] = num_c[i * M + m] / den_c[i];
     }
     __syncthreads();
-    for (int i = tid; i < N; i += nt) {
+    if (tid == 0) {
         double sum = 0.0;
         for (int k = 0; k < M; k++) {
             double v = c[i * M + k];
@@ -769,11 +831,31 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double *__restric
         }
         for (int k = 0; k < M; k++) c[i * M + k] /= sum;
     }
-    for (int g = tid; g < G; g += nt) {
+    __syncthreads();
+    // det = product of the (floored) variances in order, then the inverses (TF:343-346);
+    // the state's M*D values go through LDS so that the serial product does not pay a
+    // global-memory round trip per factor
+    extern __shared__ double vs[];
+    const double *src = inv_var + (size_t)i * M * D;
+    const bool staged = lds_doubles >= M * D;
+    if (staged) {
+        for (int k = tid; k < M * D; k += MS2_THREADS) vs[k] = src[k];
+        __syncthreads();
+        src = vs;
+    }
+    for (int m = tid; m < M; m += MS2_THREADS) {
+        const int g = i * M + m;
+        const double *v = staged ? src + (size_t)m * D : inv_var + (size_t)g * D;
         double d = 1.0;
-        for (int k = 0; k < D; k++) d *= inv_var[(size_t)g * D + k];
+        for (int k = 0; k < D; k++) d *= v[k];
         det[g] = d;
-        for (int k = 0; k < D; k++) inv_var[(size_t)g * D + k] = 1.0 / inv_var[(size_t)g * D + k];
+        const double den = norm2pi * sqrt(fabs(d));
+        wk[g] = c[g] / den;
+        logwk[g] = log(c[g]) - log(den);
+    }
+    for (int k = tid; k < M * D; k += MS2_THREADS) {
+        const size_t q = (size_t)i * M * D + k;
+        inv_var[q] = 1.0 / (staged ? vs[k] : inv_var[q]);
     }
 }
 

@@ -34,9 +34,10 @@ constexpr int EM_XR = 16;          // frame-tile doubles per lane: 16*D/64, D <=
 // Gaussians (0 beyond D); oglob[d] = mean of all means (grid = NT + D blocks).
 __global__ void __launch_bounds__(64)
 k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__restrict__ mean,
-                  double *__restrict__ offs, double *__restrict__ oglob)
+                  double *__restrict__ offs, double *__restrict__ oglob, int *__restrict__ anyflag)
 {
     const int q = blockIdx.x, t = threadIdx.x;
+    if (q == 0 && t == 0) anyflag[0] = 0; // k_prepare_mfma (next in the stream) raises it
     if (q < NT) {
         for (int d = t; d < DP; d += 64) {
             double o = 0.0;
@@ -77,7 +78,8 @@ __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
                                const double *__restrict__ wk, const double *__restrict__ offs,
                                const double *__restrict__ oglob, double *__restrict__ Wm,
                                double *__restrict__ wkp, int *__restrict__ gmap,
-                               double *__restrict__ condp, double *__restrict__ condg)
+                               double *__restrict__ condp, double *__restrict__ condg,
+                               int *__restrict__ anyflag)
 {
     const int gp = blockIdx.x * blockDim.x + threadIdx.x;
     if (gp >= NT * 16) return;
@@ -106,20 +108,9 @@ __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
     Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0; // multiplies the constant 1
     condp[gp] = real ? c0 : 0.0;
     condg[gp] = real ? cg : 0.0;
-}
-
-// anyflag[0] = 1 when some Gaussian is too ill-conditioned for the expanded statistics
-// (then the vector-ALU k_mixstats runs as well and supplies those Gaussians' sums)
-__global__ void k_any_flag(int n, const double *__restrict__ condg, int *__restrict__ anyflag)
-{
-    __shared__ int sh;
-    if (threadIdx.x == 0) sh = 0;
-    __syncthreads();
-    int f = 0;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) f |= condg[k] > COND_MAX;
-    if (f) atomicOr(&sh, 1);
-    __syncthreads();
-    if (threadIdx.x == 0) anyflag[0] = sh;
+    // some Gaussian too ill-conditioned for the expanded statistics: the vector-ALU
+    // k_mixstats then runs as well and supplies those Gaussians' sums
+    if (real && cg > COND_MAX) atomicOr(anyflag, 1);
 }
 
 // calc_symbol_probab + calc_gaus (TF:1749-1841) for 16 frames x TC Gaussian tiles per
@@ -395,46 +386,6 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
                     }
         }
         __syncthreads();
-    }
-}
-
-// sums[k] = sum_p part[p][k], p ascending within 4 interleaved slices, then a fixed tree
-__global__ void __launch_bounds__(256)
-k_sum_partials(long long n, int P, const double *__restrict__ part, double *__restrict__ sums)
-{
-    __shared__ double sh[256];
-    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long long k = (long long)blockIdx.x * 64 + e;
-    double v = 0.0;
-    if (k < n)
-        for (int p = sl; p < P; p += 4) v += part[(size_t)p * n + k];
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    if (sl == 0 && k < n) sums[k] = (sh[e] + sh[64 + e]) + (sh[128 + e] + sh[192 + e]);
-}
-
-// expanded sums -> the reference's accumulators (layout of include/ghmm.h); Gaussians
-// flagged by condg keep the sums the vector-ALU kernel produced for them
-__global__ void __launch_bounds__(256)
-k_finish_mix(int N, int M, int D, int DP, int NT, int ES, const double *__restrict__ sums,
-             const int *__restrict__ gmap, const double *__restrict__ condg,
-             const double *__restrict__ oglob, const double *__restrict__ mean,
-             double *__restrict__ num_c, double *__restrict__ num_mu, double *__restrict__ num_var)
-{
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int D1 = D + 1;
-    if (k >= (long long)NT * 16 * D1) return;
-    const int gp = (int)(k / D1), d = (int)(k - (long long)gp * D1);
-    const int g = gmap[gp];
-    if (g < 0 || condg[gp] > COND_MAX) return;
-    const double *S = sums + (size_t)gp * ES;
-    const double S0 = S[D];
-    if (d == D) {
-        num_c[g] = S0;
-    } else {
-        const double o = oglob[d], mu = mean[(size_t)g * D + d] - o;
-        num_mu[(size_t)g * D + d] = S[d] + o * S0;
-        num_var[(size_t)g * D + d] = (S[DP + d] - 2.0 * mu * S[d]) + mu * mu * S0;
     }
 }
 
