@@ -701,12 +701,46 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const int chunks = (m->NT + m->TC - 1) / m->TC;
         long long gx = (ntf + EM_WAVES - 1) / EM_WAVES;
         if (gx > ctx->cus) gx = ctx->cus; // one 8-wave block per CU, chunks in grid.y
+        // scheduled variant: compile-time K steps (D = 39 -> KS = 20) and mixture padding,
+        // Mp <= 16.  It returns at once when the model holds an ill-conditioned Gaussian
+        // (anyflag, set on the device by k_prepare_mfma); the generic kernel launched right
+        // after it returns at once when it does not — no host round trip either way.
+        const bool sched = m->Mp <= 16 && m->DP == 40;
+        const size_t lds_s = m->em_lds + (size_t)m->TC * 16 * (sizeof(double) + sizeof(int));
         {
             kscope ks(ctx, GHMM_K_EMISSION);
+            if (sched) {
+#define GHMM_EMS(MP, PO)                                                                          \
+    do {                                                                                          \
+        static bool attr_##MP##_##PO = false;                                                     \
+        if (!attr_##MP##_##PO) {                                                                  \
+            (void)hipFuncSetAttribute((const void *)k_emission_sched<20, MP, PO>,                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  \
+            attr_##MP##_##PO = true;                                                              \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gx, (unsigned)chunks), \
+                           dim3(EM_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,   \
+                           m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap, ctx->b, post,     \
+                           ctx->sink, m->anyflag);                                                \
+    } while (0)
+#define GHMM_EMS2(MP)                                                                             \
+    do {                                                                                          \
+        if (post) GHMM_EMS(MP, true);                                                             \
+        else GHMM_EMS(MP, false);                                                                 \
+    } while (0)
+                switch (m->Mp) {
+                case 1: GHMM_EMS2(1); break;
+                case 2: GHMM_EMS2(2); break;
+                case 4: GHMM_EMS2(4); break;
+                case 8: GHMM_EMS2(8); break;
+                default: GHMM_EMS2(16); break;
+                }
+            }
             hipLaunchKernelGGL(k_emission_mfma, dim3((unsigned)gx, (unsigned)chunks),
                                dim3(EM_WAVES * WAVE), m->em_lds, ctx->stream, m->N, m->M, m->Mp, m->D,
                                m->DP, m->NT, m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap,
-                               m->condg, m->mean, m->inv_var, ctx->b, post);
+                               m->condg, m->mean, m->inv_var, ctx->b, post,
+                               sched ? m->anyflag : (const int *)nullptr);
         }
         ctx->b_is_log = false;
         return launch_ok("k_emission_mfma");

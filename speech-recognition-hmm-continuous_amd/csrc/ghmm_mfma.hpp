@@ -128,9 +128,10 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                 const double *__restrict__ oglob, const double *__restrict__ wkp,
                 const int *__restrict__ gmap, const double *__restrict__ condg,
                 const double *__restrict__ mean, const double *__restrict__ inv_var,
-                double *__restrict__ b, double *__restrict__ post)
+                double *__restrict__ b, double *__restrict__ post, const int *__restrict__ only_if)
 {
     extern __shared__ double lds[];
+    if (only_if && only_if[0] == 0) return; // k_emission_sched has done the job
     const int KS = DP / 2, XS = 2 * DP + 1, G = N * M;
     double *Wl = lds;                                // [TC][KS][64]
     double *xl = Wl + (size_t)TC * KS * 64;          // [EM_WAVES][16][XS]
@@ -264,6 +265,149 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------- emission, scheduled
+// Same computation as k_emission_mfma for the common, well-conditioned case (no
+// flagged tile in the chunk, Mp <= 16), with compile-time K steps and mixture padding so
+// that a tile's epilogue (exp, state sums, posteriors, stores: ~280 vector-ALU
+// instructions) is one branch-free basic block that the scheduler interleaves with the
+// NEXT tile's 64-cycle f64 MFMAs: the matrix pipe and the vector ALU then work at the
+// same time inside one wave instead of taking turns.
+//   - stores never branch: lanes without an output write to a sink
+//   - v / b_i is a reciprocal (hardware seed + two Newton steps) after an exact
+//     power-of-two rescale of tiny or huge b_i; 0 when b_i == 0 (TF:1773-1778)
+template <int MP> __device__ inline double segment_sum_t(double v)
+{
+    if (MP >= 2) v += dpp_f64<DPP_QUAD_XOR1>(v);
+    if (MP >= 4) v += dpp_f64<DPP_QUAD_XOR2>(v);
+    if (MP >= 8) v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    if (MP >= 16) v += dpp_f64<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+template <int KS, int MP, bool POST>
+__global__ void __launch_bounds__(EM_WAVES *WAVE, 2)
+k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double *__restrict__ X,
+                 const double *__restrict__ Wm, const double *__restrict__ oglob,
+                 const double *__restrict__ wkp, const int *__restrict__ gmap,
+                 double *__restrict__ b, double *__restrict__ post, double *__restrict__ sink,
+                 const int *__restrict__ anyflag)
+{
+    extern __shared__ double lds[];
+    if (anyflag[0]) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
+    constexpr int DP = 2 * KS, XS = 2 * DP + 1;
+    constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : 4;
+    const int G = N * M;
+    double *Wl = lds;                                // [TC][KS][64]
+    double *xl = Wl + (size_t)TC * KS * 64;          // [EM_WAVES][16][XS]
+    double *wkl = xl + (size_t)EM_WAVES * 16 * XS;   // [TC][16]
+    int *gml = (int *)(wkl + (size_t)TC * 16);       // [TC][16]
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int c0 = blockIdx.y * TC;
+    const int tc = (NT - c0) < TC ? (NT - c0) : TC;
+    for (int k = tid; k < tc * KS * 64; k += EM_WAVES * WAVE) Wl[k] = Wm[(size_t)c0 * KS * 64 + k];
+    for (int k = tid; k < tc * 16; k += EM_WAVES * WAVE) {
+        wkl[k] = wkp[c0 * 16 + k];
+        gml[k] = gmap[c0 * 16 + k];
+    }
+    __syncthreads();
+    double *xw = xl + w * 16 * XS;
+    const long long ntf = (F + 15) / 16;
+    const long long FD = F * D;
+    int loff[EM_XR], roff[EM_XR];
+    double oo[EM_XR];
+#pragma unroll
+    for (int u = 0; u < EM_XR; u++) {
+        const int k = l + 64 * u, r = k / D, d = k - r * D;
+        const bool in = k < 16 * D;
+        loff[u] = in ? r * XS + d : -1;
+        roff[u] = in ? k : 0;
+        oo[u] = in ? oglob[d] : 0.0;
+    }
+    double xn[EM_XR];
+    auto fetch = [&](long long tf) {
+        const long long base = tf * 16 * D;
+#pragma unroll
+        for (int u = 0; u < EM_XR; u++) {
+            long long q = base + roff[u];
+            q = q < FD ? q : FD - 1;
+            xn[u] = X[q];
+        }
+    };
+    for (int k = l; k < 16 * (2 * DP - 2 * D); k += WAVE) {
+        const int r = k / (2 * DP - 2 * D), e = k - r * (2 * DP - 2 * D);
+        const int col = e < DP - D ? D + e : DP + D + (e - (DP - D));
+        xw[r * XS + col] = (col == D) ? 1.0 : 0.0;
+    }
+    double *snk = sink + l;
+    const double *xr = xw + j * XS + kq; // A operand: frame l&15, k = 4s + (l>>4)
+    const long long tstride = (long long)gridDim.x * EM_WAVES;
+    long long tf = (long long)blockIdx.x * EM_WAVES + w;
+    fetch(tf < ntf ? tf : 0);
+
+    auto chain = [&](int ct) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const double *Wt = Wl + (size_t)ct * KS * 64 + l;
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[4 * s], Wt[s * 64], acc, 0, 0, 0);
+        return acc;
+    };
+    auto epilogue = [&](v4d acc, int ct, long long f0) {
+        const int gp = (c0 + ct) * 16 + j;
+        const double wkj = wkl[ct * 16 + j];
+        const int gm = gml[ct * 16 + j];
+        const int st = gp >> LOGMP;
+        const bool bown = ((j & (MP - 1)) == 0) && st < N;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double e = exp_emis(acc[r]) * wkj;
+            const double s = segment_sum_t<MP>(e);
+            const long long fr = f0 + kq + 4 * r;
+            const bool frok = fr < F;
+            double *pb = (bown && frok) ? b + fr * N + st : snk;
+            *pb = s;
+            if (POST) {
+                // exact power-of-two rescale keeps the reciprocal in range
+                const double sc = s < 1.0e-290 ? 0x1p600 : (s > 1.0e290 ? 0x1p-600 : 1.0);
+                const double s2 = s * sc, e2 = e * sc;
+                double rr = __builtin_amdgcn_rcp(s2);
+                rr = fma(rr, fma(-s2, rr, 1.0), rr);
+                rr = fma(rr, fma(-s2, rr, 1.0), rr);
+                const double pv = s != 0.0 ? e2 * rr : 0.0;
+                double *pp = (gm >= 0 && frok) ? post + fr * G + gm : snk;
+                *pp = pv;
+            }
+        }
+    };
+
+    for (; tf < ntf; tf += tstride) {
+        const long long f0 = tf * 16;
+#pragma unroll
+        for (int u = 0; u < EM_XR; u++)
+            if (loff[u] >= 0) {
+                const double xo = xn[u] - oo[u];
+                xw[loff[u]] = xo;
+                xw[loff[u] + DP] = xo * xo;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fetch(tf + tstride < ntf ? tf + tstride : tf);
+        v4d acc = chain(0);
+        for (int ct = 0; ct + 1 < tc; ct++) {
+            const v4d accn = chain(ct + 1);
+            epilogue(acc, ct, f0);
+            // one MFMA, its two LDS operand reads, then a slice of the epilogue
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+            }
+            acc = accn;
+        }
+        epilogue(acc, tc - 1, f0);
     }
 }
 
