@@ -706,7 +706,11 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         // (anyflag, set on the device by k_prepare_mfma); the generic kernel launched right
         // after it returns at once when it does not — no host round trip either way.
         const bool sched = m->Mp <= 16 && m->DP == 40;
-        const size_t lds_s = m->em_lds + (size_t)m->TC * 16 * (sizeof(double) + sizeof(int));
+        const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
+                             (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
+                             (size_t)m->TC * 16 * (sizeof(double) + sizeof(int));
+        long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
+        if (gxs > ctx->cus) gxs = ctx->cus;
         {
             kscope ks(ctx, GHMM_K_EMISSION);
             if (sched) {
@@ -718,8 +722,8 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  \
             attr_##MP##_##PO = true;                                                              \
         }                                                                                         \
-        hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gx, (unsigned)chunks), \
-                           dim3(EM_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,   \
+        hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
+                           dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,   \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap, ctx->b, post,     \
                            ctx->sink, m->anyflag);                                                \
     } while (0)

@@ -27,7 +27,7 @@ namespace ghmm {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr double COND_MAX = 1.0e4; // expanded-form error ~ 4*eps*cond  (<= ~5e-12)
-constexpr int EM_WAVES = 8;        // waves per emission block (one block per CU)
+constexpr int EM_WAVES = 8;        // waves per block of the generic emission kernel
 constexpr int EM_XR = 16;          // frame-tile doubles per lane: 16*D/64, D <= 64
 
 // Offsets for the expanded forms: offs[c][DP] = mean of the means of tile c's real
@@ -268,16 +268,20 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
     }
 }
 
-// ------------------------------------------------------- emission, scheduled
+// ------------------------------------------------------- emission, occupancy
 // Same computation as k_emission_mfma for the common, well-conditioned case (no
-// flagged tile in the chunk, Mp <= 16), with compile-time K steps and mixture padding so
-// that a tile's epilogue (exp, state sums, posteriors, stores: ~280 vector-ALU
-// instructions) is one branch-free basic block that the scheduler interleaves with the
-// NEXT tile's 64-cycle f64 MFMAs: the matrix pipe and the vector ALU then work at the
-// same time inside one wave instead of taking turns.
-//   - stores never branch: lanes without an output write to a sink
+// ill-conditioned Gaussian anywhere, Mp <= 16), built for 4 waves per SIMD: sixteen
+// waves per block (one block per CU) share the chunk's B fragments in LDS, every wave
+// keeps only x' = x - oglob of its 16 frames in a 5 KB slab (the squares are formed in
+// registers, one multiply per MFMA), and the kernel stays under 128 VGPRs.  While one
+// wave waits for the 64-cycle f64 matrix pipe, the other three run their epilogues
+// (exp, state sums, posteriors), so matrix pipe and vector ALU are busy together.
+//   - K steps, mixture padding and "posteriors wanted" are compile-time
+//   - the epilogue is branch-free: lanes without an output store to a sink
 //   - v / b_i is a reciprocal (hardware seed + two Newton steps) after an exact
 //     power-of-two rescale of tiny or huge b_i; 0 when b_i == 0 (TF:1773-1778)
+constexpr int EMS_WAVES = 16;
+
 template <int MP> __device__ inline double segment_sum_t(double v)
 {
     if (MP >= 2) v += dpp_f64<DPP_QUAD_XOR1>(v);
@@ -287,8 +291,34 @@ template <int MP> __device__ inline double segment_sum_t(double v)
     return v;
 }
 
+// exp_emis on four values at once: four independent dependency chains
+__device__ inline void exp_emis4(const v4d &x, double (&out)[4])
+{
+    double k[4], r[4], p[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const double xc = x[q] < -750.0 ? -750.0 : x[q];
+        k[q] = rint(xc * 1.4426950408889634074);
+        r[q] = fma(-k[q], 6.93147180369123816490e-01, xc);
+        r[q] = fma(-k[q], 1.90821492927058770002e-10, r[q]);
+        p[q] = 1.6059043836821613e-10;
+    }
+    const double cf[12] = {2.08767569878680989792e-09, 2.50521083854417187751e-08,
+                           2.75573192239858906526e-07, 2.75573192239858906526e-06,
+                           2.48015873015873015873e-05, 1.98412698412698412698e-04,
+                           1.38888888888888888889e-03, 8.33333333333333333333e-03,
+                           4.16666666666666666667e-02, 1.66666666666666666667e-01,
+                           0.5,                        1.0};
+#pragma unroll
+    for (int t = 0; t < 12; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) p[q] = fma(p[q], r[q], cf[t]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[q] = ldexp(fma(p[q], r[q], 1.0), (int)k[q]);
+}
+
 template <int KS, int MP, bool POST>
-__global__ void __launch_bounds__(EM_WAVES *WAVE, 2)
+__global__ void __launch_bounds__(EMS_WAVES *WAVE)
 k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double *__restrict__ X,
                  const double *__restrict__ Wm, const double *__restrict__ oglob,
                  const double *__restrict__ wkp, const int *__restrict__ gmap,
@@ -297,117 +327,100 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
 {
     extern __shared__ double lds[];
     if (anyflag[0]) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
-    constexpr int DP = 2 * KS, XS = 2 * DP + 1;
+    constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 1;
     constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : 4;
     const int G = N * M;
     double *Wl = lds;                                // [TC][KS][64]
-    double *xl = Wl + (size_t)TC * KS * 64;          // [EM_WAVES][16][XS]
-    double *wkl = xl + (size_t)EM_WAVES * 16 * XS;   // [TC][16]
+    double *xl = Wl + (size_t)TC * KS * 64;          // [EMS_WAVES][16][XS]
+    double *ol = xl + (size_t)EMS_WAVES * 16 * XS;   // [DP]
+    double *wkl = ol + DP;                           // [TC][16]
     int *gml = (int *)(wkl + (size_t)TC * 16);       // [TC][16]
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int c0 = blockIdx.y * TC;
     const int tc = (NT - c0) < TC ? (NT - c0) : TC;
-    for (int k = tid; k < tc * KS * 64; k += EM_WAVES * WAVE) Wl[k] = Wm[(size_t)c0 * KS * 64 + k];
-    for (int k = tid; k < tc * 16; k += EM_WAVES * WAVE) {
+    for (int k = tid; k < tc * KS * 64; k += EMS_WAVES * WAVE) Wl[k] = Wm[(size_t)c0 * KS * 64 + k];
+    for (int k = tid; k < tc * 16; k += EMS_WAVES * WAVE) {
         wkl[k] = wkp[c0 * 16 + k];
         gml[k] = gmap[c0 * 16 + k];
     }
+    for (int k = tid; k < DP; k += EMS_WAVES * WAVE) ol[k] = k < D ? oglob[k] : 0.0;
     __syncthreads();
     double *xw = xl + w * 16 * XS;
     const long long ntf = (F + 15) / 16;
     const long long FD = F * D;
-    int loff[EM_XR], roff[EM_XR];
-    double oo[EM_XR];
-#pragma unroll
-    for (int u = 0; u < EM_XR; u++) {
-        const int k = l + 64 * u, r = k / D, d = k - r * D;
-        const bool in = k < 16 * D;
-        loff[u] = in ? r * XS + d : -1;
-        roff[u] = in ? k : 0;
-        oo[u] = in ? oglob[d] : 0.0;
+    // constant columns of the slab: the 1 at column D, zeros beyond
+    for (int k = l; k < 16 * (DP - D); k += WAVE) {
+        const int r = k / (DP - D), e = k - r * (DP - D);
+        xw[r * XS + D + e] = e == 0 ? 1.0 : 0.0;
     }
-    double xn[EM_XR];
-    auto fetch = [&](long long tf) {
-        const long long base = tf * 16 * D;
-#pragma unroll
-        for (int u = 0; u < EM_XR; u++) {
-            long long q = base + roff[u];
-            q = q < FD ? q : FD - 1;
-            xn[u] = X[q];
-        }
-    };
-    for (int k = l; k < 16 * (2 * DP - 2 * D); k += WAVE) {
-        const int r = k / (2 * DP - 2 * D), e = k - r * (2 * DP - 2 * D);
-        const int col = e < DP - D ? D + e : DP + D + (e - (DP - D));
-        xw[r * XS + col] = (col == D) ? 1.0 : 0.0;
-    }
+    const int q64 = 64 / D, r64 = 64 - q64 * D; // element index step 64 in (row, column) form
     double *snk = sink + l;
     const double *xr = xw + j * XS + kq; // A operand: frame l&15, k = 4s + (l>>4)
-    const long long tstride = (long long)gridDim.x * EM_WAVES;
-    long long tf = (long long)blockIdx.x * EM_WAVES + w;
-    fetch(tf < ntf ? tf : 0);
-
-    auto chain = [&](int ct) {
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        const double *Wt = Wl + (size_t)ct * KS * 64 + l;
-#pragma unroll
-        for (int s = 0; s < KS; s++)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[4 * s], Wt[s * 64], acc, 0, 0, 0);
-        return acc;
-    };
-    auto epilogue = [&](v4d acc, int ct, long long f0) {
-        const int gp = (c0 + ct) * 16 + j;
-        const double wkj = wkl[ct * 16 + j];
-        const int gm = gml[ct * 16 + j];
-        const int st = gp >> LOGMP;
-        const bool bown = ((j & (MP - 1)) == 0) && st < N;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double e = exp_emis(acc[r]) * wkj;
-            const double s = segment_sum_t<MP>(e);
-            const long long fr = f0 + kq + 4 * r;
-            const bool frok = fr < F;
-            double *pb = (bown && frok) ? b + fr * N + st : snk;
-            *pb = s;
-            if (POST) {
-                // exact power-of-two rescale keeps the reciprocal in range
-                const double sc = s < 1.0e-290 ? 0x1p600 : (s > 1.0e290 ? 0x1p-600 : 1.0);
-                const double s2 = s * sc, e2 = e * sc;
-                double rr = __builtin_amdgcn_rcp(s2);
-                rr = fma(rr, fma(-s2, rr, 1.0), rr);
-                rr = fma(rr, fma(-s2, rr, 1.0), rr);
-                const double pv = s != 0.0 ? e2 * rr : 0.0;
-                double *pp = (gm >= 0 && frok) ? post + fr * G + gm : snk;
-                *pp = pv;
-            }
-        }
-    };
-
-    for (; tf < ntf; tf += tstride) {
+    const long long tstride = (long long)gridDim.x * EMS_WAVES;
+    for (long long tf = (long long)blockIdx.x * EMS_WAVES + w; tf < ntf; tf += tstride) {
         const long long f0 = tf * 16;
+        {
+            // the wave's 16 x D frame tile is contiguous in HBM; lane l moves elements
+            // l + 64u (clamped addresses, never predicated).  No register prefetch: with
+            // four waves per SIMD the other waves cover this latency.
+            const long long base = f0 * D + l;
+            double xn[EM_XR];
 #pragma unroll
-        for (int u = 0; u < EM_XR; u++)
-            if (loff[u] >= 0) {
-                const double xo = xn[u] - oo[u];
-                xw[loff[u]] = xo;
-                xw[loff[u] + DP] = xo * xo;
+            for (int u = 0; u < EM_XR; u++) {
+                long long q = base + 64 * u;
+                q = q < FD ? q : FD - 1;
+                xn[u] = X[q];
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fetch(tf + tstride < ntf ? tf + tstride : tf);
-        v4d acc = chain(0);
-        for (int ct = 0; ct + 1 < tc; ct++) {
-            const v4d accn = chain(ct + 1);
-            epilogue(acc, ct, f0);
-            // one MFMA, its two LDS operand reads, then a slice of the epilogue
+            int r = l / D, d = l - r * D;
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+            for (int u = 0; u < EM_XR; u++) {
+                if (l + 64 * u < 16 * D) xw[r * XS + d] = xn[u] - ol[d];
+                r += q64;
+                d += r64;
+                if (d >= D) {
+                    d -= D;
+                    r++;
+                }
             }
-            acc = accn;
         }
-        epilogue(acc, tc - 1, f0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
+        for (int ct = 0; ct < tc; ct++) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const double *Wt = Wl + (size_t)ct * KS * 64 + l;
+#pragma unroll 5
+            for (int s = 0; s < Q; s++) {
+                const double a1 = xr[4 * s];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Wt[s * 64], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * a1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+            }
+            const int gp = (c0 + ct) * 16 + j;
+            const double wkj = wkl[ct * 16 + j];
+            const int gm = gml[ct * 16 + j];
+            const int st = gp >> LOGMP;
+            const bool bown = ((j & (MP - 1)) == 0) && st < N;
+            double e[4];
+            exp_emis4(acc, e);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                e[r] *= wkj;
+                const double sm = segment_sum_t<MP>(e[r]);
+                const long long fr = f0 + kq + 4 * r;
+                const bool frok = fr < F;
+                double *pb = (bown && frok) ? b + fr * N + st : snk;
+                *pb = sm;
+                if (POST) {
+                    // exact power-of-two rescale keeps the reciprocal in range
+                    const double sc = sm < 1.0e-290 ? 0x1p600 : (sm > 1.0e290 ? 0x1p-600 : 1.0);
+                    const double s2 = sm * sc, e2 = e[r] * sc;
+                    double rr = __builtin_amdgcn_rcp(s2);
+                    rr = fma(rr, fma(-s2, rr, 1.0), rr);
+                    rr = fma(rr, fma(-s2, rr, 1.0), rr);
+                    const double pv = sm != 0.0 ? e2 * rr : 0.0;
+                    double *pp = (gm >= 0 && frok) ? post + fr * G + gm : snk;
+                    *pp = pv;
+                }
+            }
+        }
     }
 }
 
