@@ -62,7 +62,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the GMM-HMM path has no CPU fallback")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        backend = os.environ.get("GHMM_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        kw = {"device_id": torch.device(f"cuda:{local}")} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+    # ONE explicit (non-default) stream carries every kernel of the library AND the
+    # all-reduce: torch's default stream has handle 0, which the C ABI would read as "make
+    # your own stream", and then nothing would order the collective against the E-step.
+    stream = torch.cuda.Stream(device=local)
+    torch.cuda.set_stream(stream)
 
     N, M, D, U, T = args.states, args.mix, args.dim, args.utts, args.frames
     # this rank's utterances of the conceptual corpus [rank*U, (rank+1)*U)
@@ -71,7 +78,8 @@ def main():
     X = G.synth_utterances(mean, std, lens, first_utt=rank * U)
     start = G.synth_start_model(mean, std, 0.05)
     Xd = torch.from_numpy(X).to(f"cuda:{local}")          # frames resident in HBM
-    ctx = G.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    assert stream.cuda_stream != 0
+    ctx = G.Context(local, stream=stream.cuda_stream)
     ctx.set_option(G.OPT_KERNELS, args.kernels)
     model = ctx.model(start)
     corpus = ctx.corpus_from_device(Xd.data_ptr(), lens, D)
@@ -127,7 +135,7 @@ def main():
             roofline = {
                 "kernel": "k_emission", "bound": "hbm", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": emission_traffic(frames_rank, N, M, D),
                 "avg_kernel_ms": round(emis_ms, 5),
                 "bytes_per_frame": bytes_per_frame, "frames_per_launch": frames_rank,
                 "f64_tflops": round(flops_per_frame * frames_rank / (emis_ms * 1e-3) / 1e12, 3),
@@ -157,6 +165,19 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def emission_traffic(frames, N, M, D):
+    """HBM bytes per emission launch from the committed rocprofv3 PMC pass of this same
+    workload (profiles/emission_traffic.json; counters cannot be read from inside the
+    process).  None when the shape on the command line is not the profiled one."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "emission_traffic.json")))
+    except OSError:
+        return None
+    if t.get("frames_per_launch") != frames or (N, M, D) != (10, 8, 39):
+        return None
+    return t["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(G, start, X, lens, budget_s):

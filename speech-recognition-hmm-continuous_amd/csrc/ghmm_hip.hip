@@ -344,7 +344,7 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
         hipLaunchKernelGGL(k_prepare_offsets, dim3((unsigned)(m->NT + m->D)), dim3(64), 0, ctx->stream,
                            m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob,
                            m->anyflag);
-        hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)((m->NT * 16 + 63) / 64)), dim3(64), 0,
+        hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)(m->NT * 16)), dim3(64), 0,
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
                            m->wk, m->offs, m->oglob, m->Wm, m->wkp, m->gmap, m->condp, m->condg,
                            m->anyflag);
@@ -705,7 +705,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         // Mp <= 16.  It returns at once when the model holds an ill-conditioned Gaussian
         // (anyflag, set on the device by k_prepare_mfma); the generic kernel launched right
         // after it returns at once when it does not — no host round trip either way.
-        const bool sched = m->Mp <= 16 && m->DP == 40;
+        const bool sched = (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
         const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
                              (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
                              (size_t)m->TC * 16 * (sizeof(double) + sizeof(int));
@@ -737,7 +737,9 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
                 case 2: GHMM_EMS2(2); break;
                 case 4: GHMM_EMS2(4); break;
                 case 8: GHMM_EMS2(8); break;
-                default: GHMM_EMS2(16); break;
+                case 16: GHMM_EMS2(16); break;
+                case 32: GHMM_EMS2(32); break;
+                default: GHMM_EMS2(64); break;
                 }
             }
             hipLaunchKernelGGL(k_emission_mfma, dim3((unsigned)gx, (unsigned)chunks),

@@ -67,31 +67,29 @@ k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__r
     }
 }
 
-// One thread per padded Gaussian gp = 16*c + j (state gp / Mp, mixture gp % Mp).
+// One 64-thread block per padded Gaussian gp = 16*c + j (state gp / Mp, mixture gp % Mp),
+// threads over the coefficient index.
 //   Wm[c][s][lane]  B fragments in lane order: row kk = 4s + (lane>>4), col lane&15
 //                   rows 0..DP-1 multiply [x'_0..x'_{D-1}, 1, 0..], rows DP.. multiply x'^2
 //   wkp[gp], gmap[gp] (-1 = padding); condg = sum_d inv_d mu'_d^2 with mu' = mu - oglob,
 //   the cancellation measure of the expanded forms (condp: the same around the tile's
 //   own offset, kept for diagnostics)
-__global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
-                               const double *__restrict__ mean, const double *__restrict__ inv_var,
-                               const double *__restrict__ wk, const double *__restrict__ offs,
-                               const double *__restrict__ oglob, double *__restrict__ Wm,
-                               double *__restrict__ wkp, int *__restrict__ gmap,
-                               double *__restrict__ condp, double *__restrict__ condg,
-                               int *__restrict__ anyflag)
+__global__ void __launch_bounds__(64)
+k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__restrict__ mean,
+               const double *__restrict__ inv_var, const double *__restrict__ wk,
+               const double *__restrict__ offs, const double *__restrict__ oglob,
+               double *__restrict__ Wm, double *__restrict__ wkp, int *__restrict__ gmap,
+               double *__restrict__ condp, double *__restrict__ condg, int *__restrict__ anyflag)
 {
-    const int gp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gp >= NT * 16) return;
+    __shared__ double sh0[64], sh1[64];
+    const int gp = blockIdx.x, t = threadIdx.x;
     const int c = gp >> 4, j = gp & 15, KS = DP / 2;
     const int i = gp / Mp, m = gp % Mp;
     const bool real = (i < N) && (m < M);
     const int g = real ? i * M + m : -1;
-    gmap[gp] = g;
-    wkp[gp] = real ? wk[g] : 0.0;
     double *Wc = Wm + (size_t)c * KS * 64;
     double c0 = 0.0, cg = 0.0;
-    for (int d = 0; d < DP; d++) {
+    for (int d = t; d < DP; d += 64) {
         double bc = 0.0, ac = 0.0;
         if (real && d < D) {
             const double mraw = mean[(size_t)g * D + d], iv = inv_var[(size_t)g * D + d];
@@ -105,12 +103,27 @@ __global__ void k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP,
         const int k2 = DP + d;
         Wc[(k2 >> 2) * 64 + (k2 & 3) * 16 + j] = ac;
     }
-    Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0; // multiplies the constant 1
-    condp[gp] = real ? c0 : 0.0;
-    condg[gp] = real ? cg : 0.0;
-    // some Gaussian too ill-conditioned for the expanded statistics: the vector-ALU
-    // k_mixstats then runs as well and supplies those Gaussians' sums
-    if (real && cg > COND_MAX) atomicOr(anyflag, 1);
+    sh0[t] = cg;
+    sh1[t] = c0;
+    __syncthreads();
+    for (int k = 32; k > 0; k >>= 1) {
+        if (t < k) {
+            sh0[t] += sh0[t + k];
+            sh1[t] += sh1[t + k];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        cg = sh0[0];
+        gmap[gp] = g;
+        wkp[gp] = real ? wk[g] : 0.0;
+        Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0; // multiplies the constant 1
+        condp[gp] = real ? sh1[0] : 0.0;
+        condg[gp] = real ? cg : 0.0;
+        // some Gaussian too ill-conditioned for the expanded forms: k_emission_mfma's direct
+        // form and the vector-ALU k_mixstats then take over for it
+        if (real && cg > COND_MAX) atomicOr(anyflag, 1);
+    }
 }
 
 // calc_symbol_probab + calc_gaus (TF:1749-1841) for 16 frames x TC Gaussian tiles per
@@ -270,7 +283,7 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
 
 // ------------------------------------------------------- emission, occupancy
 // Same computation as k_emission_mfma for the common, well-conditioned case (no
-// ill-conditioned Gaussian anywhere, Mp <= 16), built for 4 waves per SIMD: sixteen
+// ill-conditioned Gaussian anywhere, Mp a power of two <= 64), built for 4 waves per SIMD: sixteen
 // waves per block (one block per CU) share the chunk's B fragments in LDS, every wave
 // keeps only x' = x - oglob of its 16 frames in a 5 KB slab (the squares are formed in
 // registers, one multiply per MFMA), and the kernel stays under 128 VGPRs.  While one
@@ -328,7 +341,8 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     extern __shared__ double lds[];
     if (anyflag[0]) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
     constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 1;
-    constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : 4;
+    constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : MP == 16 ? 4 : MP == 32 ? 5 : 6;
+    constexpr int MPL = MP < 16 ? MP : 16, TPS = MP <= 16 ? 1 : MP / 16;
     const int G = N * M;
     double *Wl = lds;                                // [TC][KS][64]
     double *xl = Wl + (size_t)TC * KS * 64;          // [EMS_WAVES][16][XS]
@@ -384,26 +398,32 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
-        for (int ct = 0; ct < tc; ct++) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const double *Wt = Wl + (size_t)ct * KS * 64 + l;
+        // a state's mixtures fill MPL adjacent lanes of TPS consecutive tiles
+        for (int ct = 0; ct < tc; ct += TPS) {
+            double e[TPS][4];
+#pragma unroll
+            for (int tt = 0; tt < TPS; tt++) {
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                const double *Wt = Wl + (size_t)(ct + tt) * KS * 64 + l;
 #pragma unroll 5
-            for (int s = 0; s < Q; s++) {
-                const double a1 = xr[4 * s];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Wt[s * 64], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * a1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                for (int s = 0; s < Q; s++) {
+                    const double a1 = xr[4 * s];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Wt[s * 64], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * a1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                }
+                exp_emis4(acc, e[tt]);
+                const double wkj = wkl[(ct + tt) * 16 + j];
+#pragma unroll
+                for (int r = 0; r < 4; r++) e[tt][r] *= wkj;
             }
-            const int gp = (c0 + ct) * 16 + j;
-            const double wkj = wkl[ct * 16 + j];
-            const int gm = gml[ct * 16 + j];
-            const int st = gp >> LOGMP;
-            const bool bown = ((j & (MP - 1)) == 0) && st < N;
-            double e[4];
-            exp_emis4(acc, e);
+            const int st = ((c0 + ct) * 16 + j) >> LOGMP;
+            const bool bown = ((j & (MPL - 1)) == 0) && st < N;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                e[r] *= wkj;
-                const double sm = segment_sum_t<MP>(e[r]);
+                double tot = e[0][r];
+#pragma unroll
+                for (int tt = 1; tt < TPS; tt++) tot += e[tt][r];
+                const double sm = segment_sum_t<MPL>(tot);
                 const long long fr = f0 + kq + 4 * r;
                 const bool frok = fr < F;
                 double *pb = (bown && frok) ? b + fr * N + st : snk;
@@ -411,13 +431,17 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 if (POST) {
                     // exact power-of-two rescale keeps the reciprocal in range
                     const double sc = sm < 1.0e-290 ? 0x1p600 : (sm > 1.0e290 ? 0x1p-600 : 1.0);
-                    const double s2 = sm * sc, e2 = e[r] * sc;
+                    const double s2 = sm * sc;
                     double rr = __builtin_amdgcn_rcp(s2);
                     rr = fma(rr, fma(-s2, rr, 1.0), rr);
                     rr = fma(rr, fma(-s2, rr, 1.0), rr);
-                    const double pv = sm != 0.0 ? e2 * rr : 0.0;
-                    double *pp = (gm >= 0 && frok) ? post + fr * G + gm : snk;
-                    *pp = pv;
+                    rr = sm != 0.0 ? rr * sc : 0.0;
+#pragma unroll
+                    for (int tt = 0; tt < TPS; tt++) {
+                        const int gm = gml[(ct + tt) * 16 + j];
+                        double *pp = (gm >= 0 && frok) ? post + fr * G + gm : snk;
+                        *pp = e[tt][r] * rr;
+                    }
                 }
             }
         }

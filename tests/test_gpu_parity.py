@@ -460,3 +460,71 @@ def test_config4_shape_64_mixtures(G, ctx):
     assert_close(stats.download(), ref, what="64-mixture stats")
     for o in (model, corpus, stats):
         o.close()
+
+
+# ------------------------------------------------------------- two ranks, one GPU
+
+def _rank_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from _load import load_pkg
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    G, em = pkg.ghmm, pkg.em
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream(device=0)
+    torch.cuda.set_stream(stream)
+    hm, X, lens = synth_case(G, 10, 8, 39, [90, 120, 65, 77, 101, 64, 88])
+    lo, hi = em.shard_range(len(lens), rank, world)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    ctx = G.Context(0, stream=stream.cuda_stream)
+    model = ctx.model(hm)
+    corpus = ctx.corpus(X[off[lo]:off[hi]], lens[lo:hi])
+    be = em.HipBackend(G, ctx, model, corpus, torch=torch)
+    drv = em.EMDriver(be, dist)
+    trace = []
+    for _ in range(4):
+        drv.step()
+        trace.append(be.loglik())
+    q.put((rank, [a.copy() for a in model.get().arrays()], trace))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank(G, ctx):
+    """The bench's N > 1 path (EMDriver + HipBackend + a torch tensor aliasing the
+    statistics, all on one explicit stream) with two processes sharing this GPU and a
+    gloo all-reduce standing in for RCCL: same model as one rank on the whole corpus."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    hm, X, lens = synth_case(G, 10, 8, 39, [90, 120, 65, 77, 101, 64, 88])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    trace = []
+    for _ in range(4):
+        ctx.estep(model, corpus, stats)
+        trace.append(stats.download()[-2])
+        ctx.mstep(model, stats)
+    one = model.get().arrays()
+    for rank, arrays, tr in res:
+        assert_close(tr, trace, rtol=1e-11, what=f"rank {rank} loglik trace")
+        for a, b in zip(arrays, one):
+            assert_close(a, b, rtol=1e-9, what=f"rank {rank} model")
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)   # identical statistics -> identical redundant M-steps
+    for o in (model, corpus, stats):
+        o.close()
