@@ -58,7 +58,7 @@ struct ghmm_ctx {
            cap_pvar = 0, cap_psi = 0, cap_path = 0, cap_pm = 0, cap_sums = 0, cap_sinv = 0, cap_sink = 0;
     double *b = nullptr, *post = nullptr, *alpha = nullptr, *beta = nullptr, *gamma = nullptr;
     double *scale = nullptr, *sinv = nullptr, *lognorm = nullptr, *loglik = nullptr;
-    double *sink = nullptr; // 64 doubles that idle lanes read and write instead of branching
+    double *sink = nullptr; // [0,64): idle lanes' stores land here; [64,128): zeros they read
     double *part_xi = nullptr, *part_dena = nullptr, *part_denc = nullptr;
     double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr, *sums = nullptr;
     unsigned char *psi = nullptr;
@@ -653,8 +653,8 @@ static int ws_frames(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c, b
     if ((rc = dev_grow(&ctx->scale, &ctx->cap_scale, F))) return rc;
     if ((rc = dev_grow(&ctx->sinv, &ctx->cap_sinv, F))) return rc;
     if (!ctx->sink) {
-        if ((rc = dev_grow(&ctx->sink, &ctx->cap_sink, (size_t)WAVE))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->sink, 0, WAVE * sizeof(double), ctx->stream));
+        if ((rc = dev_grow(&ctx->sink, &ctx->cap_sink, (size_t)2 * WAVE))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->sink, 0, 2 * WAVE * sizeof(double), ctx->stream));
     }
     if ((rc = dev_grow(&ctx->lognorm, &ctx->cap_lognorm, F))) return rc;
     if ((rc = dev_grow(&ctx->loglik, &ctx->cap_loglik, (size_t)c->U))) return rc;

@@ -264,21 +264,37 @@ __device__ inline double recip_select(double s)
     return (s >= 1.0e-290 && s <= 1.0e290) ? r : r0;
 }
 
+// one Newton step on the hardware reciprocal: 2e-15 relative (measured), enough for a
+// per-step scale that is renormalised every frame; the raw reciprocal keeps 0 -> inf
+__device__ inline double recip_fast(double s)
+{
+    const double r0 = __builtin_amdgcn_rcp(s);
+    const double r = fma(r0, fma(-s, r0, 1.0), r0);
+    return (s >= 1.0e-290 && s <= 1.0e290) ? r : r0;
+}
+
 template <int L, bool BANDED> struct fwd_state {
-    double a, a_self, a_prev;
+    double a, a_self, a_prev, a_next;
     double acol[BANDED ? 1 : L];
     int N;
-    __device__ inline void step(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
+    // Banded A (what the reference's trainer always produces): a 2-term update.  (Taking
+    // the 16-lane sum off this chain via sum_j alpha^_{t-1}(j) g_j(t) was measured slower:
+    // a lone wave per SIMD is bound by instruction count, ~13 cycles each, not by the chain.)
+    __device__ inline void step_banded(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
     {
-        double aux;
-        if (BANDED) {
-            aux = group_up1<L>(a) * a_prev + a * a_self;
-        } else {
-            aux = 0.0;
+        const double v = fma(a, a_self, group_up1<L>(a) * a_prev) * bt;
+        const double s = group_sum<L>(v);
+        const double c = recip_fast(s);
+        a = v * c;
+        *pa = a;
+        *pcs = (i == 0) ? c : s;
+    }
+    __device__ inline void step_dense(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
+    {
+        double aux = 0.0;
 #pragma unroll
-            for (int j = 0; j < L; j++)
-                if (j < N) aux += __shfl(a, j, L) * acol[j];
-        }
+        for (int j = 0; j < L; j++)
+            if (j < N) aux += __shfl(a, j, L) * acol[BANDED ? 0 : j];
         const double v = aux * bt;
         const double s = group_sum<L>(v);
         const double c = recip_select(s);
@@ -298,6 +314,7 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     st.N = N;
     st.a_self = act ? A[i * N + i] : 0.0;
     st.a_prev = (act && i > 0) ? A[(i - 1) * N + i] : 0.0;
+    st.a_next = (act && i + 1 < N) ? A[i * N + i + 1] : 0.0;
     if (!BANDED) {
 #pragma unroll
         for (int j = 0; j < L; j++) st.acol[BANDED ? 0 : j] = (act && j < N) ? A[j * N + i] : 0.0;
@@ -308,15 +325,17 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     const int da = act ? N : 0;
     double *pcs = (i == 0) ? su : (i == 1 ? si : sink);
     const int dc = (i < 2) ? 1 : 0;
-    const double *pb = act ? bu + i : sink; // frame 0 of b (idle lanes: the sink, stride 0)
+    const double *pb = act ? bu + i : sink + WAVE; // frame 0 of b (idle lanes: zeros, stride 0)
     const int db = act ? N : 0;
     // b of frame f, clamped into the utterance: loads are never predicated (a load under
     // a branch makes hipcc wait vmcnt(0) at every step)
+    // (idle lanes read the zero half of the sink buffer, which nothing writes: no `act ?`
+    // here, it would predicate the load)
     auto bget = [&](int f) { return pb[(size_t)(f < T ? f : T - 1) * db]; };
 
     // t = 0
     {
-        const double a0 = ((i == 0) ? 1.0 : 0.0) * (act ? bget(0) : 0.0);
+        const double a0 = ((i == 0) ? 1.0 : 0.0) * bget(0);
         const double s = group_sum<L>(a0);
         const double c = recip_select(s);
         st.a = a0 * c;
@@ -332,10 +351,18 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
         double bn[PF];
 #pragma unroll
         for (int k = 0; k < PF; k++) bn[k] = bget(t + PF + k);
+        if (BANDED) {
 #pragma unroll
-        for (int k = 0; k < PF; k++) {
-            st.step(bq[k], pa, pcs, i);
-            pa += da; pcs += dc;
+            for (int k = 0; k < PF; k++) {
+                st.step_banded(bq[k], pa, pcs, i);
+                pa += da; pcs += dc;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                st.step_dense(bq[k], pa, pcs, i);
+                pa += da; pcs += dc;
+            }
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) bq[k] = bn[k];
@@ -343,7 +370,11 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
 #pragma unroll
     for (int k = 0; k < PF - 1; k++)
         if (t + k < T) {
-            st.step(bq[k], pa, pcs, i);
+            if (BANDED) {
+                st.step_banded(bq[k], pa, pcs, i);
+            } else {
+                st.step_dense(bq[k], pa, pcs, i);
+            }
             pa += da; pcs += dc;
         }
     return st.a;
@@ -420,20 +451,20 @@ template <int L, bool BANDED> struct bwd_state {
             for (int j = 0; j < L; j++)
                 if (j < N) aux += arow[j] * __shfl(w, j, L);
         }
-        xi[0] += al * aband[0] * w;
-        xi[1] += al * aband[1] * wd;
+        // xi band sums without the constant a_{i,i+o}: it multiplies the finished sum
+        xi[0] = fma(al, w, xi[0]);
+        xi[1] = fma(al, wd, xi[1]);
 #pragma unroll
         for (int o = 2; o <= MAX_DELTA; o++)
             if (o <= delta) {
                 double wj = __shfl_down(w, o, L);
-                xi[o] += (i + o < N) ? al * aband[o] * wj : 0.0;
+                xi[o] += (i + o < N) ? al * wj : 0.0;
             }
         be = aux * c;
-        const double g = al * be * sv;
+        const double g = (al * sv) * be;
         *pbe = be;
         *pg = g;
         dena += g;
-        denc += g;
     }
 };
 
@@ -464,7 +495,7 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
     const int dn = act ? N : 0;
     // frame-indexed readers, clamped into the utterance (never predicated); lanes without
     // a state read / write the sink with stride 0
-    const double *pa0 = act ? au + i : sink, *pb0 = act ? bu + i : sink;
+    const double *pa0 = act ? au + i : sink + WAVE, *pb0 = act ? bu + i : sink + WAVE;
     auto clampf = [&](int f) { return (size_t)(f < 0 ? 0 : f); };
     double *pbe = act ? beu + (size_t)(T - 1) * N + i : sink;
     double *pg = act ? gu + (size_t)(T - 1) * N + i : sink;
@@ -474,7 +505,7 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
         const double g = (act ? pa0[(size_t)(T - 1) * dn] : 0.0) * st.be * si[T - 1];
         *pbe = st.be;
         *pg = g;
-        st.denc += g;
+        st.denc = g; // gamma_{T-1}: in den_c (t < T, TF:1660) but not in den_a (t < T-1, TF:1618)
     }
     // queues for step t (descending from T-2): b[t+1], alpha[t], c[t], 1/c[t]
     double qb[PF], qa[PF], qc[PF], qs[PF];
@@ -514,12 +545,11 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
             st.step(qb[k], qa[k], qc[k], qs[k], pbe, pg, i);
             pbe -= dn; pg -= dn;
         }
-    // gamma_{T-1} belongs to den_c only (TF:1618 sums t < T-1, TF:1660 sums t < T):
-    // dena was accumulated for t <= T-2 only, as required
     if (act) {
-        for (int o = 0; o <= delta; o++) part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o] = st.xi[o];
+        for (int o = 0; o <= delta; o++)
+            part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o] = st.aband[o] * st.xi[o];
         part_dena[(size_t)u * N + i] = st.dena;
-        part_denc[(size_t)u * N + i] = st.denc;
+        part_denc[(size_t)u * N + i] = st.dena + st.denc;
     }
 }
 
