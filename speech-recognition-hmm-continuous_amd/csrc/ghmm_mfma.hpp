@@ -489,6 +489,13 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
         dn[n] = (k < 2 && d < D) ? d : 0;
         on[n] = (k < 2 && d < D) ? oglob[d] : 0.0;
     }
+    double k0[NE], k1[NE], k2[NE];
+#pragma unroll
+    for (int n = 0; n < NE; n++) {
+        k0[n] = kind[n] == 2 ? 1.0 : 0.0;
+        k1[n] = kind[n] == 0 ? 1.0 : 0.0;
+        k2[n] = kind[n] == 1 ? 1.0 : 0.0;
+    }
     v4d acc[CT][NE];
 #pragma unroll
     for (int c = 0; c < CT; c++)
@@ -531,11 +538,12 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
 #pragma unroll
         for (int u = 0; u < MSM_PD; u++) {
             if (st + u < s1) {
+                // feature = k0 + k1 x' + k2 x'^2 with (k0,k1,k2) fixed per lane: no branches
                 double ft[NE];
 #pragma unroll
                 for (int n = 0; n < NE; n++) {
                     const double xo = xq[u][n] - on[n];
-                    ft[n] = kind[n] == 0 ? xo : (kind[n] == 1 ? xo * xo : (kind[n] == 2 ? 1.0 : 0.0));
+                    ft[n] = fma(xo, fma(xo, k2[n], k1[n]), k0[n]);
                 }
 #pragma unroll
                 for (int c = 0; c < CT; c++)
