@@ -907,7 +907,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         // matrix-core statistics: one partial per block, one block per CU
         const int chunks = (m->NT + m->CT - 1) / m->CT;
         Pm = ctx->cus;
-        const long long steps = (c->F + 3) / 4;
+        const long long steps = c->F / 4;
         if (steps < (long long)Pm * MSM_WAVES) Pm = (int)((steps + MSM_WAVES - 1) / MSM_WAVES);
         if (Pm < 1) Pm = 1;
         nsum = (size_t)m->NT * 16 * m->NE * 16;

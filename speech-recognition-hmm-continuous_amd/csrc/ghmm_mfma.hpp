@@ -459,6 +459,14 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
 // from HBM/L2 in 128-B row segments, prefetched one k-step ahead.  The four waves of
 // a block fold their tiles through LDS in wave order and the block writes ONE partial;
 // k_sum_partials adds the partials in block order (bitwise reproducible).
+// a 64-bit value that is the same in every lane, moved to scalar registers
+__device__ inline long long uniform64(long long v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+
 constexpr int MSM_WAVES = 4;
 constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
@@ -502,56 +510,97 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
 #pragma unroll
         for (int n = 0; n < NE; n++) acc[c][n] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    // this wave's frames: ranges of whole k-steps (4 frames), dealt evenly
+    // this wave's frames: ranges of whole k-steps (4 frames), dealt evenly; the last,
+    // possibly partial k-step of the corpus is done apart (masked) by the last wave
     const long long nwaves = (long long)gridDim.x * MSM_WAVES;
     const long long wi = (long long)blockIdx.x * MSM_WAVES + w;
-    const long long steps = (F + 3) / 4;
+    const long long steps = F / 4; // whole k-steps
     const long long s0 = steps * wi / nwaves, s1 = steps * (wi + 1) / nwaves;
 
-    // operands are fetched MSM_PD k-steps ahead (a ring of register stages, statically
-    // indexed): with one wave per SIMD nothing else hides the HBM latency
-    double wq[MSM_PD][CT], xq[MSM_PD][NE];
-    // every load is unconditional (addresses clamped into the arrays, results masked):
-    // a load under a branch makes hipcc wait vmcnt(0) and the prefetch ring collapses
     int gmC[CT];
-#pragma unroll
-    for (int c = 0; c < CT; c++) gmC[c] = gmA[c] >= 0 ? gmA[c] : 0;
-#pragma unroll
-    for (int c = 0; c < CT; c++) stA[c] = stA[c] < N ? stA[c] : 0;
     double mk[CT]; // 1 for a real Gaussian, 0 for padding: masks by multiplication, so
                    // that hipcc cannot sink the loads under a branch
 #pragma unroll
-    for (int c = 0; c < CT; c++) mk[c] = gmA[c] >= 0 ? 1.0 : 0.0;
-    auto load = [&](long long st, double *wo, double *xo) {
-        long long t = st * 4 + kq;
-        const double okf = (st < s1 && t < F) ? 1.0 : 0.0;
-        t = t < F ? t : F - 1;
+    for (int c = 0; c < CT; c++) {
+        gmC[c] = gmA[c] >= 0 ? gmA[c] : 0;
+        stA[c] = stA[c] < N ? stA[c] : 0;
+        mk[c] = gmA[c] >= 0 ? 1.0 : 0.0;
+    }
+    auto mfmas = [&](const double *wv, const double *xv) {
+        // feature = k0 + k1 x' + k2 x'^2 with (k0,k1,k2) fixed per lane: no branches
+        double ft[NE];
+#pragma unroll
+        for (int n = 0; n < NE; n++) {
+            const double xo = xv[n] - on[n];
+            ft[n] = fma(xo, fma(xo, k2[n], k1[n]), k0[n]);
+        }
 #pragma unroll
         for (int c = 0; c < CT; c++)
-            wo[c] = gamma[t * N + stA[c]] * post[t * G + gmC[c]] * (mk[c] * okf);
 #pragma unroll
-        for (int n = 0; n < NE; n++) xo[n] = X[t * D + dn[n]];
+            for (int n = 0; n < NE; n++)
+                acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], ft[n], acc[c][n], 0, 0, 0);
     };
+    // Software pipeline over k-steps: operands are fetched MSM_PD k-steps ahead.  Addresses
+    // are a wave-uniform base (scalar registers) plus a 32-bit per-lane element offset that
+    // advances by a constant per step: one 32-bit add per load, no address rebuild, no
+    // predication (hipcc then counts vmcnt instead of draining it).  Past the wave's last
+    // step the offsets stop advancing, so the run-ahead re-reads valid data.  With one
+    // wave per SIMD nothing else hides the HBM latency.
+    if (s0 < s1) {
+        const long long fw = s0 * 4; // first frame of this wave (wave-uniform)
+        const double *gw = gamma + uniform64(fw * N);
+        const double *pw = post + uniform64(fw * G);
+        const double *xw = X + uniform64(fw * D);
+        unsigned og[CT], op[CT], ox[NE];
 #pragma unroll
-    for (int u = 0; u < MSM_PD; u++) load(s0 + u, wq[u], xq[u]);
-    for (long long st = s0; st < s1; st += MSM_PD) {
+        for (int c = 0; c < CT; c++) {
+            og[c] = (unsigned)(kq * N + stA[c]);
+            op[c] = (unsigned)(kq * G + gmC[c]);
+        }
 #pragma unroll
-        for (int u = 0; u < MSM_PD; u++) {
-            if (st + u < s1) {
-                // feature = k0 + k1 x' + k2 x'^2 with (k0,k1,k2) fixed per lane: no branches
-                double ft[NE];
+        for (int n = 0; n < NE; n++) ox[n] = (unsigned)(kq * D + dn[n]);
+        const long long nst = s1 - s0;
+        long long ld = 0; // stages loaded so far
+        double wq[MSM_PD][CT], xq[MSM_PD][NE];
+        auto load = [&](double *wo, double *xo) {
 #pragma unroll
-                for (int n = 0; n < NE; n++) {
-                    const double xo = xq[u][n] - on[n];
-                    ft[n] = fma(xo, fma(xo, k2[n], k1[n]), k0[n]);
-                }
+            for (int c = 0; c < CT; c++) wo[c] = gw[og[c]] * pw[op[c]] * mk[c];
 #pragma unroll
-                for (int c = 0; c < CT; c++)
+            for (int n = 0; n < NE; n++) xo[n] = xw[ox[n]];
+            ld++;
+            const unsigned adv = ld < nst ? 4u : 0u; // wave-uniform
 #pragma unroll
-                    for (int n = 0; n < NE; n++)
-                        acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq[u][c], ft[n], acc[c][n], 0, 0, 0);
+            for (int c = 0; c < CT; c++) {
+                og[c] += adv * (unsigned)N;
+                op[c] += adv * (unsigned)G;
             }
-            load(st + u + MSM_PD, wq[u], xq[u]);
+#pragma unroll
+            for (int n = 0; n < NE; n++) ox[n] += adv * (unsigned)D;
+        };
+#pragma unroll
+        for (int u = 0; u < MSM_PD; u++) load(wq[u], xq[u]);
+        for (long long st = 0; st < nst; st += MSM_PD) {
+#pragma unroll
+            for (int u = 0; u < MSM_PD; u++) {
+                if (st + u < nst) mfmas(wq[u], xq[u]);
+                load(wq[u], xq[u]);
+            }
+        }
+    }
+    // the corpus' last, partial k-step: lanes of frames past the end contribute zeros
+    {
+        const bool tail = (F & 3) != 0 && wi == nwaves - 1; // uniform per wave
+        if (tail) {
+            long long t = steps * 4 + kq;
+            const double okf = t < F ? 1.0 : 0.0;
+            t = t < F ? t : F - 1;
+            double wv[CT], xv[NE];
+#pragma unroll
+            for (int c = 0; c < CT; c++)
+                wv[c] = gamma[t * N + stA[c]] * post[t * G + gmC[c]] * (mk[c] * okf);
+#pragma unroll
+            for (int n = 0; n < NE; n++) xv[n] = X[t * D + dn[n]];
+            mfmas(wv, xv);
         }
     }
     // fold the block's waves in wave order, then write the block's partial

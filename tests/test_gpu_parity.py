@@ -282,6 +282,32 @@ def test_estep_against_oracle(G, ctx, N, M, D, lens, dense):
         o.close()
 
 
+@pytest.mark.parametrize("tier", [1, 2])
+def test_both_kernel_tiers(G, ctx, tier, load_case):
+    """GHMM_OPT_KERNELS: 1 = vector-ALU kernels only, 2 = matrix-core kernels; both must
+    reproduce the reference dumps (well-conditioned and needle-component models) and agree
+    with each other far inside the tolerance."""
+    ctx.set_option(G.OPT_KERNELS, tier)
+    try:
+        for name in ("synth39_m8", "synth39_m8_refinit", "bundled13_m3", "synth39_m64"):
+            case = load_case(name)
+            model, corpus = ctx.model(case.model0), ctx.corpus(case.X, case.lens)
+            stats = ctx.stats(case.N, case.M, case.D)
+            ctx.estep(model, corpus, stats)
+            F = corpus.frames
+            assert_close(ctx.fetch(G.BUF_B, (F, case.N)), case.frames("b"), what=f"{name} b")
+            assert_close(ctx.fetch(G.BUF_POST, (F, case.N * case.M)), case.frames("post"),
+                         what=f"{name} post")
+            got = G.split_stats(stats.download(), case.N, case.M, case.D)
+            ref = G.split_stats(case.stats(), case.N, case.M, case.D)
+            for k in ref:
+                assert_close(got[k], ref[k], what=f"{name} stats.{k}")
+            for o in (model, corpus, stats):
+                o.close()
+    finally:
+        ctx.set_option(G.OPT_KERNELS, 0)
+
+
 def test_ten_em_iterations_track_the_oracle(G, ctx):
     """Fixed iteration count (the benchmark mode): the per-iteration log-likelihood and
     the final model stay within 1e-7 of the oracle over 10 E+M steps."""
