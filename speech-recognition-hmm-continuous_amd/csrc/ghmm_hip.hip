@@ -861,12 +861,41 @@ extern "C" int ghmm_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
 // -------------------------------------------------------------- statistics
 
 template <int CT, int NE>
-static void launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int P, int chunks)
+static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int P, int chunks)
 {
-    const size_t lds = (size_t)CT * NE * 4 * 64 * sizeof(double);
-    hipLaunchKernelGGL((k_mixstats_mfma<CT, NE>), dim3((unsigned)P, (unsigned)chunks),
-                       dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT,
-                       c->F, c->X, ctx->gamma, ctx->post, m->gmap, m->oglob, ctx->part_m);
+    const size_t fold = (size_t)CT * NE * 4 * 64 * sizeof(double);
+    // staged variant: every chunk of CT tiles must map to an even-aligned, even-length run of
+    // real Gaussians (true when no mixture padding: Mp == M, M even) and N <= 16
+    const int G = m->N * m->M;
+    const bool staged = m->Mp == m->M && (m->M % 2) == 0 && m->N <= 16 && (G % 2) == 0 &&
+                        ((CT * 16) % 2) == 0 && ctx->kernels != 3;
+    if (staged) {
+        const int GWmax = CT * 16 < G ? CT * 16 : G;
+        size_t stage = (size_t)MSM_WAVES * (16 * (NE * 16 + GWmax + m->N) + m->DP) * sizeof(double);
+        size_t lds = stage > fold ? stage : fold;
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_mixstats_mfma<CT, NE, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr = true;
+        }
+        if (lds <= 150 * 1024) {
+            // one launch per chunk so that gmin / GW are plain arguments (chunks == 1 at 10x8)
+            for (int ch = 0; ch < chunks; ch++) {
+                const int gmin = ch * CT * 16;
+                int GW = G - gmin < CT * 16 ? G - gmin : CT * 16;
+                hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true>), dim3((unsigned)P, 1u),
+                                   dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
+                                   m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
+                                   m->gmap + 0, m->oglob, ctx->part_m);
+            }
+            return GHMM_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, false>), dim3((unsigned)P, (unsigned)chunks),
+                       dim3(MSM_WAVES * WAVE), fold, ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT,
+                       c->F, 0, 0, c->X, ctx->gamma, ctx->post, m->gmap, m->oglob, ctx->part_m);
+    return GHMM_OK;
 }
 
 static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *s)
@@ -907,7 +936,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         // matrix-core statistics: one partial per block, one block per CU
         const int chunks = (m->NT + m->CT - 1) / m->CT;
         Pm = ctx->cus;
-        const long long steps = c->F / 4;
+        const long long steps = c->F / 16;
         if (steps < (long long)Pm * MSM_WAVES) Pm = (int)((steps + MSM_WAVES - 1) / MSM_WAVES);
         if (Pm < 1) Pm = 1;
         nsum = (size_t)m->NT * 16 * m->NE * 16;
@@ -915,17 +944,17 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         {
             kscope ks(ctx, GHMM_K_MIXSTATS);
             switch (m->NE) {
-            case 1: launch_mixstats_mfma<8, 1>(ctx, m, c, Pm, chunks); break;
-            case 2: launch_mixstats_mfma<8, 2>(ctx, m, c, Pm, chunks); break;
-            case 3: launch_mixstats_mfma<8, 3>(ctx, m, c, Pm, chunks); break;
-            case 4: launch_mixstats_mfma<6, 4>(ctx, m, c, Pm, chunks); break;
-            case 5: launch_mixstats_mfma<5, 5>(ctx, m, c, Pm, chunks); break;
-            case 6: launch_mixstats_mfma<4, 6>(ctx, m, c, Pm, chunks); break;
-            case 7: launch_mixstats_mfma<3, 7>(ctx, m, c, Pm, chunks); break;
-            default: launch_mixstats_mfma<3, 8>(ctx, m, c, Pm, chunks); break;
+            case 1: rc = launch_mixstats_mfma<8, 1>(ctx, m, c, Pm, chunks); break;
+            case 2: rc = launch_mixstats_mfma<8, 2>(ctx, m, c, Pm, chunks); break;
+            case 3: rc = launch_mixstats_mfma<8, 3>(ctx, m, c, Pm, chunks); break;
+            case 4: rc = launch_mixstats_mfma<6, 4>(ctx, m, c, Pm, chunks); break;
+            case 5: rc = launch_mixstats_mfma<5, 5>(ctx, m, c, Pm, chunks); break;
+            case 6: rc = launch_mixstats_mfma<4, 6>(ctx, m, c, Pm, chunks); break;
+            case 7: rc = launch_mixstats_mfma<3, 7>(ctx, m, c, Pm, chunks); break;
+            default: rc = launch_mixstats_mfma<3, 8>(ctx, m, c, Pm, chunks); break;
             }
         }
-        if ((rc = launch_ok("k_mixstats_mfma"))) return rc;
+        if (rc || (rc = launch_ok("k_mixstats_mfma"))) return rc;
     }
     if (P > 0) {
         // vector-ALU statistics: the whole job on that tier, or (matrix-core tier) only

@@ -470,17 +470,23 @@ __device__ inline long long uniform64(long long v)
 constexpr int MSM_WAVES = 4;
 constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
-template <int CT, int NE>
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// STAGED = true: frames go HBM -> registers -> LDS in 16-frame stages with fully
+// coalesced 16-byte-per-lane loads (one stage ahead), MFMA operands come from LDS.
+// Needs G, gmin, GW even (16-byte alignment of the posterior rows) and N <= 16.
+// STAGED = false: operands straight from HBM, 8 bytes per lane (any shape).
+template <int CT, int NE, bool STAGED>
 __global__ void __launch_bounds__(MSM_WAVES *WAVE, 1)
-k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
+k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gmin, int GW,
                 const double *__restrict__ X, const double *__restrict__ gamma,
                 const double *__restrict__ post, const int *__restrict__ gmap,
                 const double *__restrict__ oglob, double *__restrict__ part)
 {
-    extern __shared__ double lds[]; // [CT*NE*4][64]
+    extern __shared__ double lds[]; // fold: [CT*NE*4][64]; STAGED: per-wave frame stages
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int G = N * M, ES = NE * 16;
-    const int c0 = blockIdx.y * CT;
+    const int c0 = STAGED ? gmin / 16 : blockIdx.y * CT; // staged: one launch per chunk
     int gmA[CT], stA[CT];
 #pragma unroll
     for (int c = 0; c < CT; c++) {
@@ -488,33 +494,35 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
         gmA[c] = (c0 + c < NT) ? gmap[gp] : -1;
         stA[c] = gp / Mp;
     }
-    int dn[NE], kind[NE];
-    double on[NE];
+    // per-lane feature constants of the direct (non-staged) operand path; rebuilt where
+    // they are used so that they do not stay live across the staged main loop
+    int dn[NE];
+    double on[NE], k0[NE], k1[NE], k2[NE];
+    auto feature_setup = [&]() {
 #pragma unroll
-    for (int n = 0; n < NE; n++) {
-        const int e = 16 * n + j, k = e / DP, d = e - k * DP;
-        kind[n] = (k < 2 && d < D) ? k : ((k == 0 && d == D) ? 2 : 3); // 0 x', 1 x'^2, 2 one, 3 zero
-        dn[n] = (k < 2 && d < D) ? d : 0;
-        on[n] = (k < 2 && d < D) ? oglob[d] : 0.0;
-    }
-    double k0[NE], k1[NE], k2[NE];
-#pragma unroll
-    for (int n = 0; n < NE; n++) {
-        k0[n] = kind[n] == 2 ? 1.0 : 0.0;
-        k1[n] = kind[n] == 0 ? 1.0 : 0.0;
-        k2[n] = kind[n] == 1 ? 1.0 : 0.0;
-    }
+        for (int n = 0; n < NE; n++) {
+            const int e = 16 * n + j, k = e / DP, d = e - k * DP;
+            // 0: x', 1: x'^2, 2: the constant one, 3: zero padding
+            const int kind = (k < 2 && d < D) ? k : ((k == 0 && d == D) ? 2 : 3);
+            dn[n] = (k < 2 && d < D) ? d : 0;
+            on[n] = (k < 2 && d < D) ? oglob[d] : 0.0;
+            k0[n] = kind == 2 ? 1.0 : 0.0;
+            k1[n] = kind == 0 ? 1.0 : 0.0;
+            k2[n] = kind == 1 ? 1.0 : 0.0;
+        }
+    };
     v4d acc[CT][NE];
 #pragma unroll
     for (int c = 0; c < CT; c++)
 #pragma unroll
         for (int n = 0; n < NE; n++) acc[c][n] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    // this wave's frames: ranges of whole k-steps (4 frames), dealt evenly; the last,
-    // possibly partial k-step of the corpus is done apart (masked) by the last wave
+    // this wave's frames, dealt evenly in whole units (STAGED: 16-frame stages, else
+    // 4-frame k-steps); the corpus' ragged end is done apart (masked) by the last wave
     const long long nwaves = (long long)gridDim.x * MSM_WAVES;
     const long long wi = (long long)blockIdx.x * MSM_WAVES + w;
-    const long long steps = F / 4; // whole k-steps
+    constexpr int UNIT = STAGED ? 16 : 4;
+    const long long steps = F / UNIT;
     const long long s0 = steps * wi / nwaves, s1 = steps * (wi + 1) / nwaves;
 
     int gmC[CT];
@@ -540,6 +548,96 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
             for (int n = 0; n < NE; n++)
                 acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], ft[n], acc[c][n], 0, 0, 0);
     };
+    if (STAGED) {
+        // per-wave LDS stage: fx[16][XS] extended frames | ps[16][GW] | gs[16][N] | ol[DP]
+        // The stage writer turns raw frames into [x', 1, 0.., x'^2, 0..] once, so the B
+        // operand of every MFMA is a plain LDS read (no per-k-step feature arithmetic).
+        const int XS = NE * 16; // >= 2*DP; XS*2 dwords = 32 (mod 64) for odd NE: conflict-free rows
+        const int SZ = 16 * (XS + GW + N) + DP;
+        double *fx = lds + (size_t)w * SZ, *ps = fx + 16 * XS, *gs = ps + 16 * GW, *ol = gs + 16 * N;
+        for (int k = l; k < DP; k += WAVE) ol[k] = k < D ? oglob[k] : 0.0;
+        for (int k = l; k < 16 * XS; k += WAVE) { // constant columns: the 1 and the zeros
+            const int col = k % XS;
+            fx[k] = col == D ? 1.0 : 0.0;
+        }
+        // 16-byte pieces moved per stage: X 8*D, posteriors 8*GW, gamma 8*N; lane l takes
+        // pieces l + 64u.  Bounds: 8*D <= 64*NE, 8*GW <= 64*2*CT, 8*N <= 64*2.
+        constexpr int NXL = NE, NPL = 2 * CT, NGL = 2;
+        const int nxp = 8 * D, npp = 8 * GW, ngp = 8 * N, ppr = GW / 2;
+        v2d rx[NXL], rp[NPL], rg[NGL];
+        unsigned offp[NPL]; // posterior piece -> element offset inside a stage (rows strided by G)
+#pragma unroll
+        for (int u = 0; u < NPL; u++) {
+            int pc = l + 64 * u;
+            pc = pc < npp ? pc : npp - 1; // surplus lanes re-read the last piece
+            const int row = pc / ppr, c2 = pc - row * ppr;
+            offp[u] = (unsigned)(row * G + gmin + 2 * c2);
+        }
+        // where the two doubles of X piece u land: (slab offset << 8) | coefficient index
+        unsigned xa[NXL], xb[NXL];
+#pragma unroll
+        for (int u = 0; u < NXL; u++) {
+            const int e0 = 2 * (l + 64 * u), e1 = e0 + 1;
+            const int r0 = e0 / D, d0 = e0 - r0 * D, r1 = e1 / D, d1 = e1 - r1 * D;
+            xa[u] = ((unsigned)(r0 * XS + d0) << 8) | (unsigned)d0;
+            xb[u] = ((unsigned)(r1 * XS + d1) << 8) | (unsigned)d1;
+        }
+        auto fetch = [&](long long stg) {
+            const long long f = stg * 16;
+            const v2d *xsrc = (const v2d *)(X + uniform64(f * D));
+            const v2d *gsrc = (const v2d *)(gamma + uniform64(f * N));
+            const double *psrc = post + uniform64(f * G);
+#pragma unroll
+            for (int u = 0; u < NXL; u++) {
+                int pc = l + 64 * u;
+                rx[u] = xsrc[pc < nxp ? pc : nxp - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < NPL; u++) rp[u] = *(const v2d *)(psrc + offp[u]);
+#pragma unroll
+            for (int u = 0; u < NGL; u++) {
+                int pc = l + 64 * u;
+                rg[u] = gsrc[pc < ngp ? pc : ngp - 1];
+            }
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s0 < s1) fetch(s0);
+        for (long long stg = s0; stg < s1; stg++) {
+#pragma unroll
+            for (int u = 0; u < NXL; u++)
+                if (l + 64 * u < nxp) {
+                    const double x0 = rx[u][0] - ol[xa[u] & 255u], x1 = rx[u][1] - ol[xb[u] & 255u];
+                    fx[xa[u] >> 8] = x0;
+                    fx[(xa[u] >> 8) + DP] = x0 * x0;
+                    fx[xb[u] >> 8] = x1;
+                    fx[(xb[u] >> 8) + DP] = x1 * x1;
+                }
+#pragma unroll
+            for (int u = 0; u < NPL; u++)
+                if (l + 64 * u < npp) ((v2d *)ps)[l + 64 * u] = rp[u];
+#pragma unroll
+            for (int u = 0; u < NGL; u++)
+                if (l + 64 * u < ngp) ((v2d *)gs)[l + 64 * u] = rg[u];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
+            fetch(stg + 1 < s1 ? stg + 1 : stg); // in flight under this stage's MFMAs
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) {
+                const int r = 4 * q + kq;
+                double wv[CT], ft[NE];
+#pragma unroll
+                for (int c = 0; c < CT; c++)
+                    wv[c] = gs[r * N + stA[c]] * ps[r * GW + (gmC[c] - gmin)] * mk[c];
+#pragma unroll
+                for (int n = 0; n < NE; n++) ft[n] = fx[r * XS + 16 * n + j];
+#pragma unroll
+                for (int c = 0; c < CT; c++)
+#pragma unroll
+                    for (int n = 0; n < NE; n++)
+                        acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], ft[n], acc[c][n], 0, 0, 0);
+            }
+        }
+        __syncthreads(); // the stages alias the fold buffer below
+    } else
     // Software pipeline over k-steps: operands are fetched MSM_PD k-steps ahead.  Addresses
     // are a wave-uniform base (scalar registers) plus a 32-bit per-lane element offset that
     // advances by a constant per step: one 32-bit add per load, no address rebuild, no
@@ -547,6 +645,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
     // step the offsets stop advancing, so the run-ahead re-reads valid data.  With one
     // wave per SIMD nothing else hides the HBM latency.
     if (s0 < s1) {
+        feature_setup();
         const long long fw = s0 * 4; // first frame of this wave (wave-uniform)
         const double *gw = gamma + uniform64(fw * N);
         const double *pw = post + uniform64(fw * G);
@@ -587,20 +686,24 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F,
             }
         }
     }
-    // the corpus' last, partial k-step: lanes of frames past the end contribute zeros
+    // the corpus' ragged end (F mod UNIT frames): masked k-steps by the last wave; lanes of
+    // frames past the end contribute zeros
     {
-        const bool tail = (F & 3) != 0 && wi == nwaves - 1; // uniform per wave
+        const bool tail = (F % UNIT) != 0 && wi == nwaves - 1; // uniform per wave
         if (tail) {
-            long long t = steps * 4 + kq;
-            const double okf = t < F ? 1.0 : 0.0;
-            t = t < F ? t : F - 1;
-            double wv[CT], xv[NE];
+            feature_setup();
+            for (long long tb = steps * UNIT; tb < F; tb += 4) {
+                long long t = tb + kq;
+                const double okf = t < F ? 1.0 : 0.0;
+                t = t < F ? t : F - 1;
+                double wv[CT], xv[NE];
 #pragma unroll
-            for (int c = 0; c < CT; c++)
-                wv[c] = gamma[t * N + stA[c]] * post[t * G + gmC[c]] * (mk[c] * okf);
+                for (int c = 0; c < CT; c++)
+                    wv[c] = gamma[t * N + stA[c]] * post[t * G + gmC[c]] * (mk[c] * okf);
 #pragma unroll
-            for (int n = 0; n < NE; n++) xv[n] = X[t * D + dn[n]];
-            mfmas(wv, xv);
+                for (int n = 0; n < NE; n++) xv[n] = X[t * D + dn[n]];
+                mfmas(wv, xv);
+            }
         }
     }
     // fold the block's waves in wave order, then write the block's partial
