@@ -56,6 +56,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "GHMM_FORCE_DEVICE" in os.environ:   # rehearsal of the N > 1 path on a 1-GPU box (gloo)
+        local = int(os.environ["GHMM_FORCE_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():

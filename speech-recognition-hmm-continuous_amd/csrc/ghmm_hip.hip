@@ -78,7 +78,7 @@ struct ghmm_model {
     int Mp = 0, NT = 0, DP = 0, TC = 0, tps = 1;
     size_t em_lds = 0;
     bool mfma_ok = false;
-    double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *condp = nullptr;
+    double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *logwkp = nullptr, *condp = nullptr;
     double *oglob = nullptr, *condg = nullptr;
     int *gmap = nullptr, *anyflag = nullptr;
     int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
@@ -346,8 +346,8 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
                            m->anyflag);
         hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)(m->NT * 16)), dim3(64), 0,
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
-                           m->wk, m->offs, m->oglob, m->Wm, m->wkp, m->gmap, m->condp, m->condg,
-                           m->anyflag);
+                           m->wk, m->logwk, m->offs, m->oglob, m->Wm, m->wkp, m->logwkp, m->gmap,
+                           m->condp, m->condg, m->anyflag);
     }
     return launch_ok("k_prepare_mfma");
 }
@@ -391,6 +391,7 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
             size_t nw = (size_t)m->NT * (m->DP / 2) * 64;
             if ((rc = dev_alloc(&m->Wm, nw)) || (rc = dev_alloc(&m->offs, (size_t)m->NT * m->DP)) ||
                 (rc = dev_alloc(&m->wkp, (size_t)m->NT * 16)) ||
+                (rc = dev_alloc(&m->logwkp, (size_t)m->NT * 16)) ||
                 (rc = dev_alloc(&m->condp, (size_t)m->NT * 16)) ||
                 (rc = dev_alloc(&m->gmap, (size_t)m->NT * 16)) ||
                 (rc = dev_alloc(&m->condg, (size_t)m->NT * 16)) ||
@@ -417,7 +418,8 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
         (void)hipStreamSynchronize(ctx->stream);
     }
     void *bufs[] = {m->A,  m->c,    m->mean, m->inv_var, m->det,   m->wk,    m->logwk, m->logA,
-                    m->Wm, m->offs, m->wkp,  m->condp,   m->gmap,  m->oglob, m->condg, m->anyflag};
+                    m->Wm, m->offs, m->wkp,  m->condp,   m->gmap,  m->oglob, m->condg, m->anyflag,
+                    m->logwkp};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete m;
@@ -690,6 +692,42 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         return GHMM_ERR_UNSUPPORTED;
     }
     double *post = want_post ? ctx->post : nullptr;
+    const bool sched_ok = m->mfma_ok && ctx->kernels != 1 &&
+                          (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
+    if (mode == 2 && sched_ok) {
+        // log b for the Viterbi lattice on the matrix-core kernel; with an ill-conditioned
+        // Gaussian in the model it returns at once and the vector-ALU kernel below runs
+        static bool attr_set[8] = {false};
+        const long long ntf = (c->F + 15) / 16;
+        const int chunks = (m->NT + m->TC - 1) / m->TC;
+        const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
+                             (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
+                             (size_t)m->TC * 16 * (sizeof(double) + sizeof(int));
+        long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
+        if (gxs > ctx->cus) gxs = ctx->cus;
+        kscope ks(ctx, GHMM_K_EMISSION);
+#define GHMM_EML(MP, IDX)                                                                         \
+    do {                                                                                          \
+        if (!attr_set[IDX]) {                                                                     \
+            (void)hipFuncSetAttribute((const void *)k_emission_sched<20, MP, 2>,                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  \
+            attr_set[IDX] = true;                                                                 \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_emission_sched<20, MP, 2>), dim3((unsigned)gxs, (unsigned)chunks), \
+                           dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,  \
+                           m->TC, c->F, c->X, m->Wm, m->oglob, m->logwkp, m->gmap, ctx->b,       \
+                           (double *)nullptr, ctx->sink, m->anyflag);                             \
+    } while (0)
+        switch (m->Mp) {
+        case 1: GHMM_EML(1, 0); break;
+        case 2: GHMM_EML(2, 1); break;
+        case 4: GHMM_EML(4, 2); break;
+        case 8: GHMM_EML(8, 3); break;
+        case 16: GHMM_EML(16, 4); break;
+        case 32: GHMM_EML(32, 5); break;
+        default: GHMM_EML(64, 6); break;
+        }
+    }
     if (mode == 0 && m->mfma_ok && ctx->kernels != 1) {
         static bool lds_attr_set = false;
         if (!lds_attr_set) {
@@ -729,8 +767,8 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
     } while (0)
 #define GHMM_EMS2(MP)                                                                             \
     do {                                                                                          \
-        if (post) GHMM_EMS(MP, true);                                                             \
-        else GHMM_EMS(MP, false);                                                                 \
+        if (post) GHMM_EMS(MP, 1);                                                                \
+        else GHMM_EMS(MP, 0);                                                                     \
     } while (0)
                 switch (m->Mp) {
                 case 1: GHMM_EMS2(1); break;
@@ -751,20 +789,21 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         ctx->b_is_log = false;
         return launch_ok("k_emission_mfma");
     }
+    const int *only_if = (mode == 2 && sched_ok) ? m->anyflag : (const int *)nullptr;
     {
         kscope ks(ctx, GHMM_K_EMISSION);
         if (mode == 0)
             hipLaunchKernelGGL(k_emission<0>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
                                m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
-                               ctx->b, post, ctx->lognorm);
+                               ctx->b, post, ctx->lognorm, only_if);
         else if (mode == 1)
             hipLaunchKernelGGL(k_emission<1>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
                                m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
-                               ctx->b, post, ctx->lognorm);
+                               ctx->b, post, ctx->lognorm, only_if);
         else
             hipLaunchKernelGGL(k_emission<2>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
                                m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
-                               ctx->b, post, ctx->lognorm);
+                               ctx->b, post, ctx->lognorm, only_if);
     }
     ctx->b_is_log = (mode == 2);
     return launch_ok("k_emission");

@@ -50,9 +50,11 @@ __global__ void __launch_bounds__(WAVE)
 k_emission(int N, int M, int D, long long F, const double *__restrict__ X,
            const double *__restrict__ mean, const double *__restrict__ inv_var,
            const double *__restrict__ wk, const double *__restrict__ logwk,
-           double *__restrict__ b, double *__restrict__ post, double *__restrict__ lognorm)
+           double *__restrict__ b, double *__restrict__ post, double *__restrict__ lognorm,
+           const int *__restrict__ only_if)
 {
     extern __shared__ double lds[];
+    if (only_if && only_if[0] == 0) return; // the matrix-core kernel has done the job
     const int DS = D | 1;
     const int lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * WAVE;

@@ -77,8 +77,9 @@ k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__r
 __global__ void __launch_bounds__(64)
 k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__restrict__ mean,
                const double *__restrict__ inv_var, const double *__restrict__ wk,
-               const double *__restrict__ offs, const double *__restrict__ oglob,
-               double *__restrict__ Wm, double *__restrict__ wkp, int *__restrict__ gmap,
+               const double *__restrict__ logwk, const double *__restrict__ offs,
+               const double *__restrict__ oglob, double *__restrict__ Wm, double *__restrict__ wkp,
+               double *__restrict__ logwkp, int *__restrict__ gmap,
                double *__restrict__ condp, double *__restrict__ condg, int *__restrict__ anyflag)
 {
     __shared__ double sh0[64], sh1[64];
@@ -117,6 +118,7 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
         cg = sh0[0];
         gmap[gp] = g;
         wkp[gp] = real ? wk[g] : 0.0;
+        logwkp[gp] = real ? logwk[g] : -1.0e300; // padding never wins a max, exp() of it is 0
         Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0; // multiplies the constant 1
         condp[gp] = real ? sh1[0] : 0.0;
         condg[gp] = real ? cg : 0.0;
@@ -330,7 +332,18 @@ __device__ inline void exp_emis4(const v4d &x, double (&out)[4])
     for (int q = 0; q < 4; q++) out[q] = ldexp(fma(p[q], r[q], 1.0), (int)k[q]);
 }
 
-template <int KS, int MP, bool POST>
+template <int MP> __device__ inline double segment_max_t(double v)
+{
+    if (MP >= 2) v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
+    if (MP >= 4) v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
+    if (MP >= 8) v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+    if (MP >= 16) v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    return v;
+}
+
+// OUT 0: b (recogniser, RF:860-889); 1: b and posteriors (trainer, TF:1749-1783);
+// 2: log b for the Viterbi lattice, m + log(sum exp(e - m)) like the oracle's definition
+template <int KS, int MP, int OUT>
 __global__ void __launch_bounds__(EMS_WAVES *WAVE)
 k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double *__restrict__ X,
                  const double *__restrict__ Wm, const double *__restrict__ oglob,
@@ -411,13 +424,49 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Wt[s * 64], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * a1, Wt[(Q + s) * 64], acc, 0, 0, 0);
                 }
-                exp_emis4(acc, e[tt]);
                 const double wkj = wkl[(ct + tt) * 16 + j];
+                if (OUT == 2) {
+                    // wkl holds log(wk) here: keep the exponents, exponentiate after the max
 #pragma unroll
-                for (int r = 0; r < 4; r++) e[tt][r] *= wkj;
+                    for (int r = 0; r < 4; r++) e[tt][r] = acc[r] + wkj;
+                } else {
+                    exp_emis4(acc, e[tt]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) e[tt][r] *= wkj;
+                }
             }
             const int st = ((c0 + ct) * 16 + j) >> LOGMP;
             const bool bown = ((j & (MPL - 1)) == 0) && st < N;
+            if (OUT == 2) {
+                double mx[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    double m = e[0][r];
+#pragma unroll
+                    for (int tt = 1; tt < TPS; tt++) m = fmax(m, e[tt][r]);
+                    mx[r] = segment_max_t<MPL>(m);
+                }
+                v4d sum4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int tt = 0; tt < TPS; tt++) {
+                    v4d dlt;
+                    double ex[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dlt[r] = e[tt][r] - mx[r];
+                    exp_emis4(dlt, ex);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sum4[r] += ex[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double sm = segment_sum_t<MPL>(sum4[r]);
+                    const double lb = mx[r] < -1.0e299 ? -INFINITY : mx[r] + log(sm);
+                    const long long fr = f0 + kq + 4 * r;
+                    double *pb = (bown && fr < F) ? b + fr * N + st : snk;
+                    *pb = lb;
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 double tot = e[0][r];
@@ -428,7 +477,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 const bool frok = fr < F;
                 double *pb = (bown && frok) ? b + fr * N + st : snk;
                 *pb = sm;
-                if (POST) {
+                if (OUT == 1) {
                     // exact power-of-two rescale keeps the reciprocal in range
                     const double sc = sm < 1.0e-290 ? 0x1p600 : (sm > 1.0e290 ? 0x1p-600 : 1.0);
                     const double s2 = sm * sc;
