@@ -312,7 +312,9 @@ __device__ inline void exp_emis4(const v4d &x, double (&out)[4])
     double k[4], r[4], p[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const double xc = x[q] < -750.0 ? -750.0 : x[q];
+        // (a NaN exponent becomes exp(-750) = 0: the frame's densities vanish, its scale is
+        // 1/0 and the utterance's log-likelihood still ends up NaN like the reference's)
+        const double xc = fmax(x[q], -750.0);
         k[q] = rint(xc * 1.4426950408889634074);
         r[q] = fma(-k[q], 6.93147180369123816490e-01, xc);
         r[q] = fma(-k[q], 1.90821492927058770002e-10, r[q]);
@@ -467,18 +469,31 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 }
                 continue;
             }
+            // output cursors of this lane for row r = 0 (frame f0 + kq), advanced 4 frames per
+            // r; lanes without an output, and rows past the end, store to the sink: branches
+            // around the stores were measured slower than these selects
+            double *pbr = b + (f0 + kq) * N + st;
+            double *ppr[TPS];
+            bool pok[TPS];
+#pragma unroll
+            for (int tt = 0; tt < TPS; tt++) {
+                const int gm = gml[(ct + tt) * 16 + j];
+                pok[tt] = gm >= 0;
+                ppr[tt] = post + (f0 + kq) * G + (gm >= 0 ? gm : 0);
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 double tot = e[0][r];
 #pragma unroll
                 for (int tt = 1; tt < TPS; tt++) tot += e[tt][r];
                 const double sm = segment_sum_t<MPL>(tot);
-                const long long fr = f0 + kq + 4 * r;
-                const bool frok = fr < F;
-                double *pb = (bown && frok) ? b + fr * N + st : snk;
+                const bool frok = f0 + kq + 4 * r < F;
+                double *pb = (bown && frok) ? pbr + (size_t)4 * r * N : snk;
                 *pb = sm;
                 if (OUT == 1) {
-                    // exact power-of-two rescale keeps the reciprocal in range
+                    // gauss[i][j] /= b_i, 0 when b_i == 0 (TF:1773-1778): reciprocal (hardware
+                    // seed + two Newton steps = the IEEE quotient in every case measured) after
+                    // an exact power-of-two rescale of a tiny or huge b_i
                     const double sc = sm < 1.0e-290 ? 0x1p600 : (sm > 1.0e290 ? 0x1p-600 : 1.0);
                     const double s2 = sm * sc;
                     double rr = __builtin_amdgcn_rcp(s2);
@@ -487,8 +502,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                     rr = sm != 0.0 ? rr * sc : 0.0;
 #pragma unroll
                     for (int tt = 0; tt < TPS; tt++) {
-                        const int gm = gml[(ct + tt) * 16 + j];
-                        double *pp = (gm >= 0 && frok) ? post + fr * G + gm : snk;
+                        double *pp = (pok[tt] && frok) ? ppr[tt] + (size_t)4 * r * G : snk;
                         *pp = e[tt][r] * rr;
                     }
                 }
