@@ -201,6 +201,12 @@ int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *stats);
 /* Forward-algorithm score per utterance (RF:354-366): emission without
  * posteriors + alpha + log P.  Synchronises, writes loglik[U] on the host. */
 int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *loglik_host);
+/* The recogniser's whole vocabulary loop (RF:326-374) in two launches: ONE emission launch
+ * over the concatenated Gaussians of all `n_models` word models and ONE forward launch
+ * over every (model, utterance) pair.  All models must share M and D (states may
+ * differ).  loglik_host[k*U + u] = log P(utterance u | model k).  Synchronises. */
+int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_models, ghmm_corpus *c,
+                     double *loglik_host);
 /* Max-plus lattice with the reference's one-hot start (RF:249-251) and
  * final-state termination (TF:1487, TF:1549); ties take the lowest predecessor.
  * ABSENT from the reference: defined by oracle/.

@@ -1120,6 +1120,119 @@ extern "C" int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *
     return GHMM_OK;
 }
 
+extern "C" int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_models,
+                                ghmm_corpus *c, double *loglik_host)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(models && n_models > 0 && c, "null argument");
+    ARG_CHECK(loglik_host || c->U == 0, "null destination");
+    const int M = models[0]->M, D = models[0]->D;
+    int NS = 0, Nmax = 0;
+    for (int k = 0; k < n_models; k++) {
+        ARG_CHECK(models[k], "null model");
+        if (models[k]->M != M || models[k]->D != D) {
+            ghmm_set_error("ghmm_score_batch: every model must have the same M and D");
+            return GHMM_ERR_UNSUPPORTED;
+        }
+        NS += models[k]->N;
+        if (models[k]->N > Nmax) Nmax = models[k]->N;
+    }
+    if (D != c->D) {
+        ghmm_set_error("models have %d coefficients per frame, corpus has %d", D, c->D);
+        return GHMM_ERR_ARG;
+    }
+    if (Nmax > 64) {
+        ghmm_set_error("%d states: the forward kernel holds one state per lane (<= 64)", Nmax);
+        return GHMM_ERR_UNSUPPORTED;
+    }
+    if (c->U == 0) return GHMM_OK;
+    // the concatenated model: NS states x M mixtures (transition matrix unused)
+    ghmm_model *cat = nullptr;
+    if ((rc = ghmm_model_create(ctx, NS, M, D, &cat))) return rc;
+    std::vector<fwd_model> tab((size_t)n_models);
+    size_t go = 0;
+    int so = 0;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_models && e == hipSuccess; k++) {
+        const ghmm_model *m = models[k];
+        const size_t g = (size_t)m->N * M;
+        e = hipMemcpyAsync(cat->c + go, m->c, g * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(cat->mean + go * D, m->mean, g * D * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(cat->inv_var + go * D, m->inv_var, g * D * 8, hipMemcpyDeviceToDevice,
+                               ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(cat->det + go, m->det, g * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        tab[k].A = m->A;
+        tab[k].N = m->N;
+        tab[k].bo = so;
+        go += g;
+        so += m->N;
+    }
+    fwd_model *dtab = nullptr;
+    double *dscale = nullptr, *dsinv = nullptr, *dll = nullptr;
+    if (e == hipSuccess) e = hipMemsetAsync(cat->A, 0, (size_t)NS * NS * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&dtab, tab.size() * sizeof(fwd_model));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(fwd_model), hipMemcpyHostToDevice,
+                           ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&dscale, (size_t)n_models * c->F * 8 + 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&dsinv, (size_t)n_models * c->F * 8 + 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&dll, (size_t)n_models * c->U * 8);
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (dtab) (void)hipFree(dtab);
+        if (dscale) (void)hipFree(dscale);
+        if (dsinv) (void)hipFree(dsinv);
+        if (dll) (void)hipFree(dll);
+        ghmm_model_destroy(ctx, cat);
+    };
+    if (e != hipSuccess) {
+        ghmm_set_error("ghmm_score_batch: %s", hipGetErrorString(e));
+        cleanup();
+        return GHMM_ERR_HIP;
+    }
+    if ((rc = model_prepare(ctx, cat, true)) || (rc = ws_frames(ctx, cat, c, false)) ||
+        (rc = run_emission(ctx, cat, c, ctx->robust ? 1 : 0, false))) {
+        cleanup();
+        return rc;
+    }
+    if (ctx->robust) {
+        // per-frame normalisation couples the models' densities; score them one by one
+        cleanup();
+        for (int k = 0; k < n_models; k++)
+            if ((rc = ghmm_score(ctx, models[k], c, loglik_host + (size_t)k * c->U))) return rc;
+        return GHMM_OK;
+    }
+    {
+        const int L = Nmax <= 16 ? 16 : 64, gpw = WAVE / L;
+        const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
+        kscope ks(ctx, GHMM_K_FORWARD);
+        if (L == 16)
+            hipLaunchKernelGGL(k_forward_multi<16>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
+                               ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
+                               ctx->sink);
+        else
+            hipLaunchKernelGGL(k_forward_multi<64>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
+                               ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
+                               ctx->sink);
+    }
+    rc = launch_ok("k_forward_multi");
+    if (!rc) {
+        e = hipMemcpyAsync(loglik_host, dll, (size_t)n_models * c->U * 8, hipMemcpyDeviceToHost,
+                           ctx->stream);
+        if (e != hipSuccess) {
+            ghmm_set_error("ghmm_score_batch: %s", hipGetErrorString(e));
+            rc = GHMM_ERR_HIP;
+        }
+    }
+    cleanup();
+    ctx->b_is_log = true; // the workspace b belongs to the concatenated model: not reusable
+    return rc;
+}
+
 extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_t *path_host,
                             double *score_host)
 {

@@ -310,7 +310,7 @@ template <int L, bool BANDED>
 __device__ inline double forward_run(int N, int T, int i, bool act, const double *__restrict__ A,
                                      const double *__restrict__ bu, double *__restrict__ au,
                                      double *__restrict__ su, double *__restrict__ si,
-                                     double *__restrict__ sink)
+                                     double *__restrict__ sink, int bstride)
 {
     fwd_state<L, BANDED> st;
     st.N = N;
@@ -323,12 +323,12 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     }
     // per-lane store cursors: alpha slot (stride N) or the sink (stride 0); lane 0 writes
     // c_t, lane 1 writes 1/c_t = sum_i alpha_t(i), the rest write the sink
-    double *pa = act ? au + i : sink;
-    const int da = act ? N : 0;
+    double *pa = (act && au) ? au + i : sink; // au == nullptr: scoring only, alpha^ not kept
+    const int da = (act && au) ? N : 0;
     double *pcs = (i == 0) ? su : (i == 1 ? si : sink);
     const int dc = (i < 2) ? 1 : 0;
     const double *pb = act ? bu + i : sink + WAVE; // frame 0 of b (idle lanes: zeros, stride 0)
-    const int db = act ? N : 0;
+    const int db = act ? bstride : 0;
     // b of frame f, clamped into the utterance: loads are never predicated (a load under
     // a branch makes hipcc wait vmcnt(0) at every step)
     // (idle lanes read the zero half of the sink buffer, which nothing writes: no `act ?`
@@ -408,9 +408,9 @@ k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__
     double *snk = sink + (threadIdx.x & (WAVE - 1));
     double a;
     if (banded)
-        a = forward_run<L, true>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk);
+        a = forward_run<L, true>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
     else
-        a = forward_run<L, false>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk);
+        a = forward_run<L, false>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
     // log P: the T logs are spread over the group's lanes instead of a serial loop
     __threadfence_block();
     double lp = 0.0;
@@ -421,6 +421,56 @@ k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__
     lp = group_sum<L>(lp);
     double last = __shfl(a, N - 1, L);
     if (i == 0) loglik[u] = lp + log(last);
+}
+
+// The recogniser's vocabulary loop (RF:326-374) in one launch: blockIdx.y = word model.
+// The emission densities of ALL models were computed by one launch over the concatenated
+// Gaussians (b[F][NS], model k owns columns bo_k .. bo_k + N_k - 1); every (model,
+// utterance) pair runs calc_alpha + calc_probability here.  alpha^ is not kept.
+struct fwd_model {
+    const double *A;
+    int N, bo;
+};
+
+template <int L>
+__global__ void __launch_bounds__(WAVE)
+k_forward_multi(int U, int NS, long long F, const fwd_model *__restrict__ tab,
+                const double *__restrict__ b, const long long *__restrict__ off,
+                double *__restrict__ scale, double *__restrict__ sinv,
+                double *__restrict__ loglik, double *__restrict__ sink)
+{
+    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    const int i = threadIdx.x % L;
+    const int k = blockIdx.y;
+    if (u >= U) return;
+    const fwd_model mk = tab[k];
+    const int N = mk.N;
+    const double *A = mk.A;
+    const long long f0 = off[u];
+    const int T = (int)(off[u + 1] - f0);
+    if (T <= 0) {
+        if (i == 0) loglik[(size_t)k * U + u] = 0.0;
+        return;
+    }
+    const bool act = i < N;
+    bool offband = false;
+    for (int j = 0; j < N; j++)
+        offband |= act && (A[j * N + i] != 0.0 && j != i && j != i - 1);
+    const bool banded = !__any(offband);
+    double *su = scale + (size_t)k * F + f0, *si = sinv + (size_t)k * F + f0;
+    double *snk = sink + (threadIdx.x & (WAVE - 1));
+    const double *bu = b + f0 * NS + mk.bo;
+    double a;
+    if (banded)
+        a = forward_run<L, true>(N, T, i, act, A, bu, nullptr, su, si, snk, NS);
+    else
+        a = forward_run<L, false>(N, T, i, act, A, bu, nullptr, su, si, snk, NS);
+    __threadfence_block();
+    double lp = 0.0;
+    for (int t = i; t < T; t += L) lp -= log(su[t]);
+    lp = group_sum<L>(lp);
+    double last = __shfl(a, N - 1, L);
+    if (i == 0) loglik[(size_t)k * U + u] = lp + log(last);
 }
 
 // ----------------------------------------------------------------- backward

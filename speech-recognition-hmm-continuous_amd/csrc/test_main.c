@@ -228,19 +228,35 @@ int main(int argc, char **argv)
         for (int j = 0; j < K; j++) {
             ghmm_corpus *corpus;
             if ((rc = ghmm_corpus_create(ctx, X[j], len[j], n_utt, D[j], &corpus))) die("corpus", rc);
+            /* the whole vocabulary in one batched call when the models share M and D
+               (ghmm_score_batch); model by model otherwise */
+            ghmm_model **dm = (ghmm_model **)calloc((size_t)word_number, sizeof(ghmm_model *));
+            double *all = (double *)malloc((size_t)word_number * (size_t)n_utt * sizeof(double));
+            if (!dm || !all) die("memory", GHMM_ERR_ALLOC);
+            int same = 1;
             for (int k = 0; k < word_number; k++) {
                 ghmm_host_model *m = &hm[j][k];
-                ghmm_model *dm;
                 if (m->D != D[j]) {
                     printf("model %s has %d coefficients, data has %d \n", m->word, m->D, D[j]);
                     exit(1);
                 }
-                if ((rc = ghmm_model_create(ctx, m->N, m->M, m->D, &dm))) die("model", rc);
-                if ((rc = ghmm_model_set(ctx, dm, m->A, m->c, m->mean, m->inv_var, m->det))) die("model", rc);
-                if ((rc = ghmm_score(ctx, dm, corpus, part))) die("scoring", rc);
-                for (int u = 0; u < n_utt; u++) score[(size_t)k * n_utt + u] += coef_model[j] * part[u];
-                ghmm_model_destroy(ctx, dm);
+                if (m->M != hm[j][0].M) same = 0;
+                if ((rc = ghmm_model_create(ctx, m->N, m->M, m->D, &dm[k]))) die("model", rc);
+                if ((rc = ghmm_model_set(ctx, dm[k], m->A, m->c, m->mean, m->inv_var, m->det))) die("model", rc);
             }
+            if (same) {
+                if ((rc = ghmm_score_batch(ctx, dm, word_number, corpus, all))) die("scoring", rc);
+            } else {
+                for (int k = 0; k < word_number; k++)
+                    if ((rc = ghmm_score(ctx, dm[k], corpus, all + (size_t)k * n_utt))) die("scoring", rc);
+            }
+            for (int k = 0; k < word_number; k++) {
+                for (int u = 0; u < n_utt; u++)
+                    score[(size_t)k * n_utt + u] += coef_model[j] * all[(size_t)k * n_utt + u];
+                ghmm_model_destroy(ctx, dm[k]);
+            }
+            free(dm);
+            free(all);
             ghmm_corpus_destroy(ctx, corpus);
         }
         ghmm_ctx_destroy(ctx);

@@ -79,6 +79,7 @@ SYMBOLS = {
     "ghmm_estep": (C.c_int, [_vp, _vp, _vp, _vp], True),
     "ghmm_mstep": (C.c_int, [_vp, _vp, _vp], True),
     "ghmm_score": (C.c_int, [_vp, _vp, _vp, _dp], True),
+    "ghmm_score_batch": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, _dp], True),
     "ghmm_viterbi": (C.c_int, [_vp, _vp, _vp, _ip, _dp], True),
     "ghmm_perfil_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(_dp)], False),
@@ -354,6 +355,13 @@ class Context:
     def score(self, model, corpus):
         out = np.empty(corpus.n_utt, dtype=np.float64)
         _check(self.lib.ghmm_score(self.h, model.h, corpus.h, _d(out)), self.lib)
+        return out
+
+    def score_batch(self, models, corpus):
+        """RF:326-374 for a whole vocabulary: out[k, u] = log P(utterance u | model k)."""
+        arr = (_vp * len(models))(*[m.h for m in models])
+        out = np.empty((len(models), corpus.n_utt), dtype=np.float64)
+        _check(self.lib.ghmm_score_batch(self.h, arr, len(models), corpus.h, _d(out)), self.lib)
         return out
 
     def viterbi(self, model, corpus):

@@ -377,6 +377,38 @@ def test_score_equals_training_loglik_and_oracle(G, ctx):
     corpus.close()
 
 
+def test_score_batch_is_the_vocabulary_loop(G, ctx, whole):
+    """ghmm_score_batch (one emission launch over all word models' Gaussians + one forward
+    launch over every (model, utterance) pair) = ghmm_score model by model, on the
+    reference's 13 x 13 recognition case (NaN / -inf artefacts included) and on models
+    with different state counts."""
+    models = np.load(os.path.join(GOLDEN, "train13_m1_models.npz"))
+    hms = [G.HostModel(*(models[f"{w}.{k}"] for k in ("A", "c", "mean", "inv_var", "det")))
+           for w in whole["words"]]
+    Xs = [G.perfil_read(os.path.join(GOLDEN, "perfil", fn)) for fn in whole["mean_list"]]
+    corpus = ctx.corpus(np.concatenate(Xs), [len(x) for x in Xs])
+    dms = [ctx.model(hm) for hm in hms]
+    batch = ctx.score_batch(dms, corpus)
+    single = np.stack([ctx.score(m, corpus) for m in dms])
+    assert_close(batch, single, rtol=1e-12, what="13x13 batch vs single")
+    for m in dms:
+        m.close()
+    corpus.close()
+    cases = [synth_case(G, n, 4, 13, [70, 33, 90, 64, 1], dense_A=(n == 5)) for n in (5, 9, 16)]
+    X, lens = cases[0][1], cases[0][2]
+    corpus = ctx.corpus(X, lens)
+    dms = [ctx.model(c[0]) for c in cases]
+    batch = ctx.score_batch(dms, corpus)
+    o = 0
+    for u, T in enumerate(lens):
+        for k, c in enumerate(cases):
+            assert batch[k, u] == pytest.approx(O.score(c[0], X[o:o + T]), rel=1e-10)
+        o += T
+    for m in dms:
+        m.close()
+    corpus.close()
+
+
 def test_robust_mode(G, ctx):
     """GHMM_OPT_ROBUST (per-frame max-normalised densities): same statistics where the
     reference is finite, finite scores where whole frames underflow in the reference's

@@ -42,16 +42,21 @@ def test_no_cpu_fallback(G):
 
 
 def test_product_does_not_touch_the_oracle():
-    """The oracle is test infrastructure: nothing under the package, include/ or bench's
-    product path may link or load it."""
-    for d, _, files in os.walk(PKG_DIR):
-        for fn in files:
-            if fn.endswith((".c", ".hip", ".hpp", ".h", ".py")) or fn == "Makefile":
-                txt = open(os.path.join(d, fn), errors="replace").read()
-                assert "oracle" not in txt.replace("oracle/ghmm_oracle.c", "").replace(
-                    "oracle/.", "") or fn in ("ghmm_kernels.hpp", "ghmm_hip.hip", "em.py"), fn
+    """The oracle is test infrastructure: nothing under the package or include/ may include,
+    link, dlopen or import it (comments may mention it)."""
+    import re
+    bad = re.compile(r'libghmm_oracle|oracle_lib|#\s*include\s*[<"][^>"]*oracle|dlopen|orc_[a-z_]+\s*\(')
+    for root in (PKG_DIR, os.path.join(ROOT, "include")):
+        for d, _, files in os.walk(root):
+            for fn in files:
+                if fn.endswith((".c", ".hip", ".hpp", ".h", ".py")) or fn == "Makefile":
+                    txt = open(os.path.join(d, fn), errors="replace").read()
+                    assert not bad.search(txt), f"{fn} reaches into oracle/"
     out = subprocess.run(["ldd", os.path.join(PKG_DIR, "libghmm_hip.so")], stdout=subprocess.PIPE)
     assert b"ghmm_oracle" not in out.stdout
+    for exe in ("hmm-continuous-train-fs", "recognition-continuous-test-fs"):
+        out = subprocess.run(["ldd", os.path.join(PKG_DIR, "bin", exe)], stdout=subprocess.PIPE)
+        assert b"ghmm_oracle" not in out.stdout and b"libghmm_hip" in out.stdout
 
 
 def test_command_line_usage(G):
