@@ -246,7 +246,8 @@ __device__ inline double recip_scale(double s)
     return 1.0 / s;
 }
 
-constexpr int PF = 8; // frames of b / alpha prefetched ahead of the serial recursion
+constexpr int PF = 8;   // frames of b / alpha prefetched ahead of the serial recursion
+constexpr int PFF = 16; // the same for the forward pass (one operand stream, more room)
 
 // ------------------------------------------------------------------ forward
 // calc_alpha (TF:1380-1443 = RF:739-799) with pi = one-hot at state 0 (TF:232-234)
@@ -270,9 +271,10 @@ __device__ inline double recip_select(double s)
 // per-step scale that is renormalised every frame; the raw reciprocal keeps 0 -> inf
 __device__ inline double recip_fast(double s)
 {
+    // s = 0, inf or subnormal gives NaN here where the reference's 1.0/s gives inf or 0;
+    // either way every later alpha^ of the utterance, and its log P, is NaN (0 * inf)
     const double r0 = __builtin_amdgcn_rcp(s);
-    const double r = fma(r0, fma(-s, r0, 1.0), r0);
-    return (s >= 1.0e-290 && s <= 1.0e290) ? r : r0;
+    return fma(r0, fma(-s, r0, 1.0), r0);
 }
 
 template <int L, bool BANDED> struct fwd_state {
@@ -345,32 +347,32 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
         *pcs = (i == 0) ? c : s;
         pa += da; pcs += dc;
     }
-    double bq[PF];
+    double bq[PFF];
     int t = 1;
 #pragma unroll
-    for (int k = 0; k < PF; k++) bq[k] = bget(t + k);
-    for (; t + PF <= T; t += PF) {
-        double bn[PF];
+    for (int k = 0; k < PFF; k++) bq[k] = bget(t + k);
+    for (; t + PFF <= T; t += PFF) {
+        double bn[PFF];
 #pragma unroll
-        for (int k = 0; k < PF; k++) bn[k] = bget(t + PF + k);
+        for (int k = 0; k < PFF; k++) bn[k] = bget(t + PFF + k);
         if (BANDED) {
 #pragma unroll
-            for (int k = 0; k < PF; k++) {
+            for (int k = 0; k < PFF; k++) {
                 st.step_banded(bq[k], pa, pcs, i);
                 pa += da; pcs += dc;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < PF; k++) {
+            for (int k = 0; k < PFF; k++) {
                 st.step_dense(bq[k], pa, pcs, i);
                 pa += da; pcs += dc;
             }
         }
 #pragma unroll
-        for (int k = 0; k < PF; k++) bq[k] = bn[k];
+        for (int k = 0; k < PFF; k++) bq[k] = bn[k];
     }
 #pragma unroll
-    for (int k = 0; k < PF - 1; k++)
+    for (int k = 0; k < PFF - 1; k++)
         if (t + k < T) {
             if (BANDED) {
                 st.step_banded(bq[k], pa, pcs, i);
