@@ -110,6 +110,24 @@ def test_hmm_file_both_header_widths(G, load_case, tmp_path):
     assert e.value.code == G.ERR_FORMAT
 
 
+def test_shipped_full_covariance_models_are_refused_not_misread(G):
+    """The 13 .hmm files the reference ships were written by its FULL-covariance trainer on
+    a 32-bit build: the diagonal reader must say 'bad format', not parse
+    garbage.  (Runs only where /root/reference is mounted.)"""
+    d = "/root/reference/test/test/models"
+    if not os.path.isdir(d):
+        pytest.skip("reference tree not present")
+    files = [f for f in sorted(os.listdir(d)) if f.endswith(".hmm")]
+    assert len(files) == 13
+    for fn in files:
+        word = fn[len("mean_"):-len(".hmm")]
+        # 4-byte length + word + 4 ints + A[6][6] + 6 x (1 weight + 9 means + det + 9x9 inverse)
+        assert os.path.getsize(os.path.join(d, fn)) == 4 + len(word) + 16 + 8 * (36 + 6 * 92)
+        with pytest.raises(G.GhmmError) as e:
+            G.HostModel.read(os.path.join(d, fn))
+        assert e.value.code == G.ERR_FORMAT
+
+
 @pytest.mark.parametrize("name", ["bundled186_m1", "bundled13_m3", "synth39_m8_refinit"])
 def test_initial_model_is_bit_exact_vs_reference(G, load_case, name):
     """creating_initial_model TF:732-1317 (uniform segmentation, LBG, k-means, variance
