@@ -55,12 +55,12 @@ struct ghmm_ctx {
     // workspace (grown on demand, never shrunk)
     size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
            cap_lognorm = 0, cap_loglik = 0, cap_pxi = 0, cap_pdena = 0, cap_pdenc = 0, cap_pmu = 0,
-           cap_pvar = 0, cap_psi = 0, cap_path = 0, cap_pm = 0, cap_sums = 0, cap_sinv = 0, cap_sink = 0;
+           cap_pvar = 0, cap_psi = 0, cap_path = 0, cap_pm = 0, cap_sinv = 0, cap_sink = 0;
     double *b = nullptr, *post = nullptr, *alpha = nullptr, *beta = nullptr, *gamma = nullptr;
     double *scale = nullptr, *sinv = nullptr, *lognorm = nullptr, *loglik = nullptr;
     double *sink = nullptr; // [0,64): idle lanes' stores land here; [64,128): zeros they read
     double *part_xi = nullptr, *part_dena = nullptr, *part_denc = nullptr;
-    double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr, *sums = nullptr;
+    double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr;
     unsigned char *psi = nullptr;
     int *path = nullptr;
     // shape of what the workspace currently holds (for ghmm_fetch)
@@ -223,7 +223,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     void *bufs[] = {ctx->b,       ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
-                    ctx->part_m,  ctx->sums,      ctx->sinv,      ctx->sink};
+                    ctx->part_m,  ctx->sinv,      ctx->sink};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &t : ctx->kt) {

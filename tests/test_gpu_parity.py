@@ -257,6 +257,14 @@ def synth_case(G, N, M, D, lens, perturb=0.05, first=0, dense_A=False, seed=3):
     (16, 4, 13, [70, 80], True),                                     # N = group width
     (20, 2, 9, [60, 45, 81], True),                                  # N > 16: one wave per utterance
     (6, 3, 40, [64, 128], False),                                    # even D (LDS row padding)
+    (7, 3, 39, [100, 61, 16, 15, 17], False),                        # D=39 fast kernels, M padded 3 -> 4
+    (5, 5, 39, [80, 48], True),                                      # M padded 5 -> 8, dense A
+    (3, 16, 39, [90, 33], False),                                    # one state per tile
+    (2, 32, 39, [70, 64], False),                                    # a state spans two tiles
+    (1, 1, 1, [10, 1, 3], False),                                    # the smallest model
+    (2, 5, 3, [33, 20], True),
+    (33, 2, 4, [50, 70], True),                                      # N > 16: one wave per utterance
+    (10, 8, 39, [5000, 2999], False),                                # long utterances (reference cap: 500)
 ])
 def test_estep_against_oracle(G, ctx, N, M, D, lens, dense):
     hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense)
