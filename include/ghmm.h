@@ -135,6 +135,15 @@ void ghmm_corpus_destroy(ghmm_ctx *ctx, ghmm_corpus *c);
 int64_t ghmm_corpus_frames(const ghmm_corpus *c);
 int ghmm_corpus_utterances(const ghmm_corpus *c);
 
+/* creating_initial_model (TF:732-1317) on the device, from a corpus resident in HBM:
+ * uniform segmentation, LBG splitting (x1.005 / x0.995), three nearest-mean passes per
+ * split, per-cell variance floored at 1e-5, weights floored and renormalised, one-step
+ * left-to-right transitions.  The distance / accumulation passes run on the GPU (they
+ * are the statistics kernels fed with one-hot weights), the cell bookkeeping (splitting
+ * order, empty cells) on the host.  Fills model `m` (its N, M, D).  Synchronises.
+ */
+int ghmm_model_init(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c);
+
 /* ---------------------------------------------------- sufficient statistics */
 
 /* Flat Baum-Welch accumulator vector — the ONLY thing that crosses GPUs

@@ -1105,6 +1105,144 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
     return model_prepare(ctx, m, false);
 }
 
+// creating_initial_model (TF:732-1317): distance / accumulation passes on the device (hard
+// statistics through the vector-ALU statistics kernel: direct (x - mean)^2, no expanded
+// form), cell bookkeeping on the host exactly as the reference orders it.
+extern "C" int ghmm_model_init(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_pair(m, c))) return rc;
+    ARG_CHECK(c->U > 0 && c->F > 0, "empty corpus");
+    const int N = m->N, M = m->M, D = m->D, G = N * M;
+    if ((rc = ws_frames(ctx, m, c, true)) || (rc = ws_fb(ctx, m, c))) return rc;
+    // the utterance-level partials feed k_reduce_all too; they carry nothing here
+    HIP_TRY(hipMemsetAsync(ctx->part_xi, 0, (size_t)c->U * N * (MAX_DELTA + 1) * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->part_dena, 0, (size_t)c->U * N * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->part_denc, 0, (size_t)c->U * N * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->loglik, 0, (size_t)c->U * 8, ctx->stream));
+    ghmm_stats *st = nullptr;
+    if ((rc = ghmm_stats_create(ctx, N, M, D, &st))) return rc;
+    const size_t ns = st->n;
+    std::vector<double> sv(ns), A((size_t)N * N), cw((size_t)G, 1.0 / M), cells((size_t)G * D, 0.0),
+        ones((size_t)G * D, 1.0), det1((size_t)G, 1.0), dist((size_t)G, 0.0);
+    std::vector<int> idx((size_t)M);
+    const double *num_c = sv.data() + (size_t)N * N + 2 * (size_t)N;
+    const double *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
+    // one-step left-to-right transitions, uniform over the allowed band (TF:774-806)
+    const int delta = 1;
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) {
+            double a;
+            if (j > delta + i || j < i) a = 0.0;
+            else if (delta + 1 > N - i) a = 1.0 / (double)(N - i);
+            else a = 1.0 / (double)(delta + 1);
+            A[(size_t)i * N + j] = a;
+        }
+    const int64_t saved_kernels = ctx->kernels;
+    ctx->kernels = 1; // direct-form statistics for every pass
+    auto pass = [&](int n_cells) -> int {
+        int r = ghmm_model_set(ctx, m, A.data(), cw.data(), cells.data(), ones.data(), det1.data());
+        if (r) return r;
+        {
+            kscope ks(ctx, GHMM_K_PREPARE);
+            hipLaunchKernelGGL(k_init_classify, dim3((unsigned)((c->F + 255) / 256)), dim3(256), 0,
+                               ctx->stream, N, M, D, n_cells, c->U, c->F, c->X, c->off, m->mean,
+                               ctx->gamma, ctx->post);
+        }
+        if ((r = launch_ok("k_init_classify")) || (r = run_accumulate(ctx, m, c, st))) return r;
+        if ((r = ghmm_stats_download(ctx, st, sv.data()))) return r;
+        for (int g = 0; g < G; g++) {
+            double d = 0.0;
+            for (int l = 0; l < D; l++) d += num_var[(size_t)g * D + l];
+            dist[g] = d;
+        }
+        return GHMM_OK;
+    };
+    // indices by decreasing key, adjacent-swap passes with strict '<' (TF:1289-1315)
+    auto order_desc = [&](const double *key, int n) {
+        for (int i = 0; i < n; i++) idx[i] = i;
+        bool done = false;
+        while (!done) {
+            done = true;
+            for (int i = 0; i < n - 1; i++)
+                if (key[idx[i]] < key[idx[i + 1]]) {
+                    std::swap(idx[i], idx[i + 1]);
+                    done = false;
+                }
+        }
+    };
+    auto split_cell = [&](double *ck, int from, int to) { // TF:1138
+        for (int l = 0; l < D; l++) ck[(size_t)to * D + l] = ck[(size_t)from * D + l] * 1.005;
+        for (int l = 0; l < D; l++) ck[(size_t)from * D + l] = ck[(size_t)from * D + l] * 0.995;
+    };
+    auto finish = [&](int r) {
+        ctx->kernels = saved_kernels;
+        ghmm_stats_destroy(ctx, st);
+        return r;
+    };
+    // one cell per state: the mean of the state's frames
+    if ((rc = pass(1))) return finish(rc);
+    for (int k = 0; k < N; k++)
+        for (int l = 0; l < D; l++)
+            cells[((size_t)k * M) * D + l] = num_mu[((size_t)k * M) * D + l] / num_c[(size_t)k * M];
+    int n_cells = 1;
+    while (n_cells < M) {
+        for (int k = 0; k < N; k++) {
+            double *ck = cells.data() + (size_t)k * M * D;
+            if (2 * n_cells < M) {
+                for (int i = 0; i < n_cells; i++) split_cell(ck, i, n_cells + i);
+            } else {
+                order_desc(dist.data() + (size_t)k * M, n_cells);
+                for (int i = 0; i < M - n_cells; i++) split_cell(ck, idx[i], n_cells + i);
+            }
+        }
+        n_cells = (2 * n_cells < M) ? 2 * n_cells : M;
+        for (int it = 0; it < 3; it++) { // TF:1043
+            if ((rc = pass(n_cells))) return finish(rc);
+            for (int k = 0; k < N; k++) {
+                double *ck = cells.data() + (size_t)k * M * D;
+                for (int j = 0; j < n_cells; j++)
+                    for (int l = 0; l < D; l++)
+                        ck[(size_t)j * D + l] =
+                            num_mu[((size_t)k * M + j) * D + l] / num_c[(size_t)k * M + j];
+                // empty cells are re-seeded from the cells with the largest distortion (TF:1236-1270)
+                order_desc(dist.data() + (size_t)k * M, n_cells);
+                int i = 0;
+                for (int j = 0; j < n_cells; j++)
+                    if (num_c[(size_t)k * M + j] == 0.0) split_cell(ck, idx[i++], j);
+            }
+        }
+    }
+    // per-cell variance around the final means and cell weights (TF:883-933)
+    if ((rc = pass(M))) return finish(rc);
+    std::vector<double> iv((size_t)G * D), dt((size_t)G);
+    for (int k = 0; k < N; k++) {
+        double dur = 0.0, sum = 0.0;
+        for (int j = 0; j < M; j++) dur += num_c[(size_t)k * M + j];
+        for (int j = 0; j < M; j++) {
+            const size_t g = (size_t)k * M + j;
+            double d = 1.0;
+            for (int l = 0; l < D; l++) {
+                double v = num_var[g * D + l] / num_c[g];
+                if (v < FLOOR) v = FLOOR;
+                iv[g * D + l] = v;
+            }
+            for (int l = 0; l < D; l++) d *= iv[g * D + l];
+            dt[g] = d;
+            for (int l = 0; l < D; l++) iv[g * D + l] = 1.0 / iv[g * D + l];
+            double w = num_c[g] / dur;
+            if (w < FLOOR) w = FLOOR;
+            cw[g] = w;
+            sum += w;
+        }
+        for (int j = 0; j < M; j++) cw[(size_t)k * M + j] /= sum;
+    }
+    ctx->kernels = saved_kernels;
+    rc = ghmm_model_set(ctx, m, A.data(), cw.data(), cells.data(), iv.data(), dt.data());
+    ghmm_stats_destroy(ctx, st);
+    return rc;
+}
+
 extern "C" int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *loglik_host)
 {
     int rc = use(ctx);

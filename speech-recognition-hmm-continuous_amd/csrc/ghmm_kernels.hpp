@@ -943,6 +943,56 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
     }
 }
 
+// --------------------------------------------------------------- init model
+// creating_initial_model (TF:732-1317) on the device.  Its k-means passes are "hard"
+// statistics: with gamma_t = one-hot(state that owns frame t under the uniform
+// segmentation, TF:1005-1013) and post_t = one-hot(nearest cell of that state,
+// classifying TF:1179-1215: squared Euclidean distance, strict '<', lowest cell wins
+// ties), the mixture-statistics kernels give exactly what init_mix_mean / init_mix_param
+// accumulate: num_c = vectors per cell, num_mu = their sum, sum_d num_var = the cell's
+// distortion (and, in the last pass, the per-dimension squared deviations TF:883-891).
+// One thread per frame.
+__global__ void __launch_bounds__(256)
+k_init_classify(int N, int M, int D, int n_cells, int U, long long F,
+                const double *__restrict__ X, const long long *__restrict__ off,
+                const double *__restrict__ mean, double *__restrict__ gamma,
+                double *__restrict__ post)
+{
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    // utterance of this frame: last u with off[u] <= f
+    int lo = 0, hi = U - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= f) lo = mid;
+        else hi = mid - 1;
+    }
+    const int T = (int)(off[lo + 1] - off[lo]), j = (int)(f - off[lo]);
+    // run k of an utterance of T frames: q = T/N frames, the first T%N runs one more
+    const int q = T / N, r = T % N;
+    int k;
+    if (j < r * (q + 1)) k = j / (q + 1);
+    else k = r + (q > 0 ? (j - r * (q + 1)) / q : 0);
+    const double *x = X + f * D;
+    double best = 1.0e20;
+    int cell = 0;
+    for (int c = 0; c < n_cells; c++) {
+        const double *mu = mean + ((size_t)k * M + c) * D;
+        double dist = 0.0;
+        for (int d = 0; d < D; d++) {
+            double aux = mu[d] - x[d];
+            dist += aux * aux;
+        }
+        if (dist < best) {
+            best = dist;
+            cell = c;
+        }
+    }
+    double *g = gamma + f * N, *p = post + f * (size_t)N * M;
+    for (int i = 0; i < N; i++) g[i] = i == k ? 1.0 : 0.0;
+    for (int e = 0; e < N * M; e++) p[e] = e == k * M + cell ? 1.0 : 0.0;
+}
+
 // ------------------------------------------------------------------ viterbi
 // Max-plus lattice (absent from the reference; definition in oracle/ghmm_oracle.c):
 //   delta_0(j) = (j == 0 ? 0 : -inf) + logb_j(0)

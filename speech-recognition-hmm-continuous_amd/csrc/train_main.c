@@ -127,6 +127,12 @@ int main(int argc, char **argv)
 
     ghmm_host_model hm;
     memset(&hm, 0, sizeof hm);
+    ghmm_ctx *ctx;
+    ghmm_model *model;
+    ghmm_corpus *corpus;
+    ghmm_stats *stats;
+    if ((rc = ghmm_ctx_create(0, NULL, &ctx))) die("GPU context", rc);
+    if ((rc = ghmm_corpus_create(ctx, X, len, n_utt, D, &corpus))) die("corpus", rc);
     if (initial) {
         if ((rc = ghmm_hmm_read(initial, &hm))) die("initial model", rc);
         if (hm.D != D) {
@@ -135,19 +141,23 @@ int main(int argc, char **argv)
         }
         N = hm.N;
         M = hm.M;
-    } else if ((rc = ghmm_init_model(X, len, n_utt, N, M, D, &hm))) {
-        die("creating initial model", rc);
+        if ((rc = ghmm_model_create(ctx, N, M, D, &model))) die("model", rc);
+        if ((rc = ghmm_model_set(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
+    } else {
+        /* creating_initial_model (TF:226): on the GPU from the resident corpus, or with
+           GHMM_HOST_INIT=1 by the host implementation (bit-exact with the reference) */
+        if ((rc = ghmm_host_model_alloc(&hm, N, M, D))) die("memory", rc);
+        if ((rc = ghmm_model_create(ctx, N, M, D, &model))) die("model", rc);
+        const char *hi = getenv("GHMM_HOST_INIT");
+        if (hi && *hi == '1') {
+            ghmm_host_model_free(&hm);
+            if ((rc = ghmm_init_model(X, len, n_utt, N, M, D, &hm))) die("creating initial model", rc);
+            if ((rc = ghmm_model_set(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
+        } else if ((rc = ghmm_model_init(ctx, model, corpus))) {
+            die("creating initial model", rc);
+        }
     }
     snprintf(hm.word, sizeof hm.word, "%s", word);
-
-    ghmm_ctx *ctx;
-    ghmm_model *model;
-    ghmm_corpus *corpus;
-    ghmm_stats *stats;
-    if ((rc = ghmm_ctx_create(0, NULL, &ctx))) die("GPU context", rc);
-    if ((rc = ghmm_model_create(ctx, N, M, D, &model))) die("model", rc);
-    if ((rc = ghmm_model_set(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
-    if ((rc = ghmm_corpus_create(ctx, X, len, n_utt, D, &corpus))) die("corpus", rc);
     if ((rc = ghmm_stats_create(ctx, N, M, D, &stats))) die("statistics", rc);
     size_t ns = ghmm_stats_len(N, M, D);
     double *sv = (double *)malloc(ns * sizeof(double));

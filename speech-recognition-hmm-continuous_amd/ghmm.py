@@ -57,6 +57,7 @@ SYMBOLS = {
     "ghmm_model_destroy": (None, [_vp, _vp], True),
     "ghmm_model_set": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp], True),
     "ghmm_model_get": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp], True),
+    "ghmm_model_init": (C.c_int, [_vp, _vp, _vp], True),
     "ghmm_model_dims": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)], True),
     "ghmm_corpus_create": (C.c_int, [_vp, _dp, _ip, C.c_int, C.c_int, C.POINTER(_vp)], True),
@@ -384,6 +385,11 @@ class Model:
     def set(self, hm):
         _check(self.ctx.lib.ghmm_model_set(self.ctx.h, self.h, *(_d(x) for x in hm.arrays())),
                self.ctx.lib)
+
+    def init_from(self, corpus):
+        """creating_initial_model (TF:732) on the device; returns the model as HostModel."""
+        _check(self.ctx.lib.ghmm_model_init(self.ctx.h, self.h, corpus.h), self.ctx.lib)
+        return self.get()
 
     def get(self):
         N, M, D = self.N, self.M, self.D

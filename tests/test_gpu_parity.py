@@ -98,6 +98,24 @@ def test_fused_estep_and_mstep_against_reference_dumps(G, ctx, case):
         o.close()
 
 
+@pytest.mark.parametrize("name", ["bundled186_m1", "bundled13_m3", "synth39_m8_refinit"])
+def test_device_initial_model_against_reference(G, ctx, load_case, name):
+    """ghmm_model_init = creating_initial_model TF:732-1317 with the distance/accumulation
+    passes on the GPU: the reference's own initial model (needle components, det = 1e-195,
+    included) within 1e-9 — sums are taken in a different order, nothing else differs."""
+    case = load_case(name)
+    corpus = ctx.corpus(case.X, case.lens)
+    model = ctx.model(case.model0)            # shapes only; overwritten
+    got = model.init_from(corpus)
+    for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), got.arrays(), case.model0.arrays()):
+        assert_close(a, b, rtol=1e-9, floor=0.0, what=f"{name} init.{nm}")
+    host = G.HostModel.init_from(case.X, case.lens, case.N, case.M)
+    for a, b in zip(host.arrays(), case.model0.arrays()):
+        assert np.array_equal(a, b, equal_nan=True)      # the host version is bit-exact
+    model.close()
+    corpus.close()
+
+
 @pytest.fixture(scope="module")
 def whole():
     return json.load(open(os.path.join(GOLDEN, "whole_program.json")))
