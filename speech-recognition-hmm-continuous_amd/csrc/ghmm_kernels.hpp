@@ -163,6 +163,16 @@ template <int CTRL> __device__ inline double dpp_f64(double v)
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// value of lane i ^ 4: row_shl:4 into the lanes of banks 0 and 2, row_shr:4 into banks 1 and 3
+__device__ inline double dpp_xor4_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int tl = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false);
+    int th = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
+    tl = __builtin_amdgcn_update_dpp(tl, lo, 0x114, 0xf, 0xa, false);
+    th = __builtin_amdgcn_update_dpp(th, hi, 0x114, 0xf, 0xa, false);
+    return __hiloint2double(th, tl);
+}
 constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111;
 constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
 

@@ -364,7 +364,8 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     double *ol = xl + (size_t)EMS_WAVES * 16 * XS;   // [DP]
     double *wkl = ol + DP;                           // [TC][16]
     int *gml = (int *)(wkl + (size_t)TC * 16);       // [TC][16]
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index, in a scalar register
     const int c0 = blockIdx.y * TC;
     const int tc = (NT - c0) < TC ? (NT - c0) : TC;
     for (int k = tid; k < tc * KS * 64; k += EMS_WAVES * WAVE) Wl[k] = Wm[(size_t)c0 * KS * 64 + k];
@@ -469,41 +470,106 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 }
                 continue;
             }
-            // output cursors of this lane for row r = 0 (frame f0 + kq), advanced 4 frames per
-            // r; lanes without an output, and rows past the end, store to the sink: branches
-            // around the stores were measured slower than these selects
-            double *pbr = b + (f0 + kq) * N + st;
-            double *ppr[TPS];
-            bool pok[TPS];
+            // State sums by a transposing butterfly: at the xor-1 and xor-2 levels each lane
+            // keeps only the rows whose index matches its lane bits and sends the others, so
+            // that after the sums lane j holds b_i of ONE row, r = j & 3 (MPL >= 4), or of two
+            // rows r = (j & 1) and 2 + (j & 1) (MPL == 2).  The reciprocal for the posteriors
+            // (TF:1773-1778) is then formed once per (frame, state) instead of once per lane
+            // and row, and handed back to the state's lanes by quad broadcasts.  The additions
+            // pair the same lanes as a plain butterfly: bit-identical sums.
+            constexpr int NV = MPL >= 4 ? 1 : (MPL == 2 ? 2 : 4);
+            double sv[NV];
+            {
+                double tot[4];
 #pragma unroll
-            for (int tt = 0; tt < TPS; tt++) {
-                const int gm = gml[(ct + tt) * 16 + j];
-                pok[tt] = gm >= 0;
-                ppr[tt] = post + (f0 + kq) * G + (gm >= 0 ? gm : 0);
+                for (int r = 0; r < 4; r++) {
+                    tot[r] = e[0][r];
+#pragma unroll
+                    for (int tt = 1; tt < TPS; tt++) tot[r] += e[tt][r];
+                }
+                if (MPL == 1) {
+#pragma unroll
+                    for (int r = 0; r < NV; r++) sv[r] = tot[r % 4];
+                } else {
+                    const bool o0 = (j & 1) != 0;
+                    double k0 = o0 ? tot[1] : tot[0], k1 = o0 ? tot[3] : tot[2];
+                    const double s0 = o0 ? tot[0] : tot[1], s1 = o0 ? tot[2] : tot[3];
+                    k0 += dpp_f64<DPP_QUAD_XOR1>(s0);
+                    k1 += dpp_f64<DPP_QUAD_XOR1>(s1);
+                    if (MPL == 2) {
+                        sv[0] = k0;
+                        sv[NV - 1] = k1;
+                    } else {
+                        const bool o1 = (j & 2) != 0;
+                        double kk = o1 ? k1 : k0;
+                        const double ss = o1 ? k0 : k1;
+                        kk += dpp_f64<DPP_QUAD_XOR2>(ss);
+                        if (MPL >= 8) kk += dpp_xor4_f64(kk);
+                        if (MPL >= 16) kk += dpp_f64<DPP_ROW_ROR8>(kk);
+                        sv[0] = kk;
+                    }
+                }
             }
+            // rows held by this lane: rw(v) = v-th held row; holders of b: the first lanes of
+            // the state's group (one per row)
+            const long long frow = f0 + kq;
+            const bool full = f0 + 16 <= F; // wave-uniform
+            double rrv[NV];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double tot = e[0][r];
-#pragma unroll
-                for (int tt = 1; tt < TPS; tt++) tot += e[tt][r];
-                const double sm = segment_sum_t<MPL>(tot);
-                const bool frok = f0 + kq + 4 * r < F;
-                double *pb = (bown && frok) ? pbr + (size_t)4 * r * N : snk;
+            for (int v = 0; v < NV; v++) {
+                const int rw = MPL >= 4 ? (j & 3) : (MPL == 2 ? 2 * v + (j & 1) : v);
+                const bool holder = MPL >= 4 ? (j & (MPL - 1)) < 4 : true;
+                const bool bok = holder && st < N && frow + 4 * rw < F;
+                double *pb = bok ? b + (frow + 4 * rw) * N + st : snk;
+                const double sm = sv[v];
                 *pb = sm;
                 if (OUT == 1) {
-                    // gauss[i][j] /= b_i, 0 when b_i == 0 (TF:1773-1778): reciprocal (hardware
-                    // seed + two Newton steps = the IEEE quotient in every case measured) after
-                    // an exact power-of-two rescale of a tiny or huge b_i
+                    // gauss[i][j] /= b_i, 0 when b_i == 0: reciprocal (hardware seed + two
+                    // Newton steps = the IEEE quotient in every case measured) after an exact
+                    // power-of-two rescale of a tiny or huge b_i
                     const double sc = sm < 1.0e-290 ? 0x1p600 : (sm > 1.0e290 ? 0x1p-600 : 1.0);
                     const double s2 = sm * sc;
                     double rr = __builtin_amdgcn_rcp(s2);
                     rr = fma(rr, fma(-s2, rr, 1.0), rr);
                     rr = fma(rr, fma(-s2, rr, 1.0), rr);
-                    rr = sm != 0.0 ? rr * sc : 0.0;
+                    rrv[v] = sm != 0.0 ? rr * sc : 0.0;
+                }
+            }
+            if (OUT == 1) {
+                double rr4[4];
+                if (MPL >= 4) {
+                    rr4[0] = dpp_f64<0x00>(rrv[0]); // quad_perm:[r,r,r,r]
+                    rr4[1] = dpp_f64<0x55>(rrv[0]);
+                    rr4[2] = dpp_f64<0xAA>(rrv[0]);
+                    rr4[3] = dpp_f64<0xFF>(rrv[0]);
+                } else if (MPL == 2) {
+                    rr4[0] = dpp_f64<0xA0>(rrv[0]);      // quad_perm:[0,0,2,2]: the pair's even lane
+                    rr4[1] = dpp_f64<0xF5>(rrv[0]);      // quad_perm:[1,1,3,3]: the pair's odd lane
+                    rr4[2] = dpp_f64<0xA0>(rrv[NV - 1]);
+                    rr4[3] = dpp_f64<0xF5>(rrv[NV - 1]);
+                } else {
 #pragma unroll
-                    for (int tt = 0; tt < TPS; tt++) {
-                        double *pp = (pok[tt] && frok) ? ppr[tt] + (size_t)4 * r * G : snk;
-                        *pp = e[tt][r] * rr;
+                    for (int r = 0; r < 4; r++) rr4[r] = rrv[r % NV];
+                }
+                // posterior cursor of this lane for row 0 (frame f0 + kq), 4 frames per r; a
+                // lane without an output has cursor = sink and stride 0, rows past the end of
+                // a ragged last tile go to the sink too: branches around the stores were
+                // measured slower than these selects
+#pragma unroll
+                for (int tt = 0; tt < TPS; tt++) {
+                    const int gm = gml[(ct + tt) * 16 + j];
+                    const long long off = gm >= 0 ? frow * G + gm : 0;
+                    double *pp0 = (gm >= 0 ? post : snk) + off;
+                    const long long stp = gm >= 0 ? (long long)4 * G : 0;
+                    if (full) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) pp0[r * stp] = e[tt][r] * rr4[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            double *pp = frow + 4 * r < F ? pp0 + r * stp : snk;
+                            *pp = e[tt][r] * rr4[r];
+                        }
                     }
                 }
             }
