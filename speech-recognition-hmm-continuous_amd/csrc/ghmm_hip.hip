@@ -702,7 +702,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const int chunks = (m->NT + m->TC - 1) / m->TC;
         const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
                              (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
-                             (size_t)m->TC * 16 * (sizeof(double) + sizeof(int));
+                             (size_t)m->TC * 16 * 32; // wk + cursor tables
         long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
         if (gxs > ctx->cus) gxs = ctx->cus;
         kscope ks(ctx, GHMM_K_EMISSION);
@@ -746,7 +746,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const bool sched = (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
         const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
                              (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
-                             (size_t)m->TC * 16 * (sizeof(double) + sizeof(int));
+                             (size_t)m->TC * 16 * 32; // wk + cursor tables
         long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
         if (gxs > ctx->cus) gxs = ctx->cus;
         {

@@ -310,12 +310,21 @@ template <int MP> __device__ inline double segment_sum_t(double v)
 __device__ inline void exp_emis4(const v4d &x, double (&out)[4])
 {
     double k[4], r[4], p[4];
+    int ki[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        // (a NaN exponent becomes exp(-750) = 0: the frame's densities vanish, its scale is
-        // 1/0 and the utterance's log-likelihood still ends up NaN like the reference's)
-        const double xc = fmax(x[q], -750.0);
-        k[q] = rint(xc * 1.4426950408889634074);
+        // clamp at -750 on the high word (negative doubles order like unsigned integers):
+        // one 32-bit v_min_u32, where fmax() costs two v_max_f64 (it canonicalises first).
+        // Anything in (-751, -750] underflows to exp = 0 through v_ldexp_f64 like libm;
+        // -inf and sign-bit NaNs become 0 too, a positive NaN stays NaN: either way the
+        // frame's scale is 1/0 or NaN and the utterance's log-likelihood ends up NaN like
+        // the reference's
+        const unsigned hi = (unsigned)__double2hiint(x[q]);
+        const double xc = __hiloint2double((int)(hi < 0xC0877000u ? hi : 0xC0877000u), __double2loint(x[q]));
+        // round to nearest by adding 1.5 * 2^52: the integer lands in the low mantissa bits
+        const double t = fma(xc, 1.4426950408889634074, 0x1.8p52);
+        ki[q] = __double2loint(t);
+        k[q] = t - 0x1.8p52;
         r[q] = fma(-k[q], 6.93147180369123816490e-01, xc);
         r[q] = fma(-k[q], 1.90821492927058770002e-10, r[q]);
         p[q] = 1.6059043836821613e-10;
@@ -331,7 +340,7 @@ __device__ inline void exp_emis4(const v4d &x, double (&out)[4])
 #pragma unroll
         for (int q = 0; q < 4; q++) p[q] = fma(p[q], r[q], cf[t]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) out[q] = ldexp(fma(p[q], r[q], 1.0), (int)k[q]);
+    for (int q = 0; q < 4; q++) out[q] = ldexp(fma(p[q], r[q], 1.0), ki[q]);
 }
 
 template <int MP> __device__ inline double segment_max_t(double v)
@@ -363,7 +372,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     double *xl = Wl + (size_t)TC * KS * 64;          // [EMS_WAVES][16][XS]
     double *ol = xl + (size_t)EMS_WAVES * 16 * XS;   // [DP]
     double *wkl = ol + DP;                           // [TC][16]
-    int *gml = (int *)(wkl + (size_t)TC * 16);       // [TC][16]
+    // output cursors per (tile, lane & 15): element offset {posterior, b} inside a frame row,
+    // or the distance to the lane's sink slot, and the row stride {G, N} or 0 for the sink
+    long long *offl = (long long *)(wkl + (size_t)TC * 16); // [TC][16][2]
+    unsigned *strl = (unsigned *)(offl + (size_t)TC * 32);  // [TC][16][2]
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index, in a scalar register
     const int c0 = blockIdx.y * TC;
@@ -371,7 +383,13 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     for (int k = tid; k < tc * KS * 64; k += EMS_WAVES * WAVE) Wl[k] = Wm[(size_t)c0 * KS * 64 + k];
     for (int k = tid; k < tc * 16; k += EMS_WAVES * WAVE) {
         wkl[k] = wkp[c0 * 16 + k];
-        gml[k] = gmap[c0 * 16 + k];
+        const int gm = gmap[c0 * 16 + k], jj = k & 15;
+        const int stt = (c0 * 16 + k) >> LOGMP;
+        const bool hold = (MPL >= 4 ? (jj & (MPL - 1)) < 4 : true) && stt < N;
+        offl[2 * k] = OUT != 1 ? 0 : (gm >= 0 ? (long long)gm : (sink + jj) - post);
+        offl[2 * k + 1] = hold ? (long long)stt : (sink + 16 + jj) - b;
+        strl[2 * k] = gm >= 0 ? (unsigned)G : 0u;
+        strl[2 * k + 1] = hold ? (unsigned)N : 0u;
     }
     for (int k = tid; k < DP; k += EMS_WAVES * WAVE) ol[k] = k < D ? oglob[k] : 0.0;
     __syncthreads();
@@ -510,17 +528,18 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                     }
                 }
             }
-            // rows held by this lane: rw(v) = v-th held row; holders of b: the first lanes of
-            // the state's group (one per row)
-            const long long frow = f0 + kq;
+            // rows held by this lane: rw = v-th held row; b is stored by the first lanes of the
+            // state's group (one per row), everything else goes to the sink (cursor tables)
+            const unsigned frow = (unsigned)(f0 + kq);
             const bool full = f0 + 16 <= F; // wave-uniform
+            const long long boff = offl[2 * (ct * 16 + j) + 1];
+            const unsigned bstr = strl[2 * (ct * 16 + j) + 1];
             double rrv[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 const int rw = MPL >= 4 ? (j & 3) : (MPL == 2 ? 2 * v + (j & 1) : v);
-                const bool holder = MPL >= 4 ? (j & (MPL - 1)) < 4 : true;
-                const bool bok = holder && st < N && frow + 4 * rw < F;
-                double *pb = bok ? b + (frow + 4 * rw) * N + st : snk;
+                double *pb = b + ((unsigned long long)(frow + 4 * rw) * bstr + boff);
+                if (!full) pb = (long long)frow + 4 * rw < F ? pb : snk;
                 const double sm = sv[v];
                 *pb = sm;
                 if (OUT == 1) {
@@ -557,17 +576,17 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 // measured slower than these selects
 #pragma unroll
                 for (int tt = 0; tt < TPS; tt++) {
-                    const int gm = gml[(ct + tt) * 16 + j];
-                    const long long off = gm >= 0 ? frow * G + gm : 0;
-                    double *pp0 = (gm >= 0 ? post : snk) + off;
-                    const long long stp = gm >= 0 ? (long long)4 * G : 0;
+                    const long long goff = offl[2 * ((ct + tt) * 16 + j)];
+                    const unsigned gstr = strl[2 * ((ct + tt) * 16 + j)];
+                    double *pp0 = post + ((unsigned long long)frow * gstr + goff);
+                    const unsigned long long stp = (unsigned long long)(4u * gstr);
                     if (full) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) pp0[r * stp] = e[tt][r] * rr4[r];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            double *pp = frow + 4 * r < F ? pp0 + r * stp : snk;
+                            double *pp = (long long)frow + 4 * r < F ? pp0 + r * stp : snk;
                             *pp = e[tt][r] * rr4[r];
                         }
                     }
