@@ -404,9 +404,21 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     const int q64 = 64 / D, r64 = 64 - q64 * D; // element index step 64 in (row, column) form
     double *snk = sink + l;
     const double *xr = xw + j * XS + kq; // A operand: frame l&15, k = 4s + (l>>4)
-    const long long tstride = (long long)gridDim.x * EMS_WAVES;
-    for (long long tf = (long long)blockIdx.x * EMS_WAVES + w; tf < ntf; tf += tstride) {
+    // Work units = (frame tile, group of TPS Gaussian tiles), dealt to the grid's waves in
+    // equal contiguous shares: with whole frame tiles per wave, 18 750 tiles on 4 096 waves
+    // left 42 % of the CUs idle during the last of five rounds.  A wave that starts or ends
+    // inside a frame tile loads that tile's slab like any other.
+    const int ng = (tc + TPS - 1) / TPS;
+    const long long U = ntf * ng, GWV = (long long)gridDim.x * EMS_WAVES;
+    const long long gwv = (long long)blockIdx.x * EMS_WAVES + w;
+    long long u = U * gwv / GWV;
+    const long long u1 = U * (gwv + 1) / GWV;
+    long long tf = u / ng;
+    int g0 = (int)(u - tf * ng);
+    for (; u < u1; tf++, g0 = 0) {
         const long long f0 = tf * 16;
+        const int g1 = (u1 - u) < (long long)(ng - g0) ? g0 + (int)(u1 - u) : ng;
+        u += g1 - g0;
         {
             // the wave's 16 x D frame tile is contiguous in HBM; lane l moves elements
             // l + 64u (clamped addresses, never predicated).  No register prefetch: with
@@ -433,7 +445,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
         // a state's mixtures fill MPL adjacent lanes of TPS consecutive tiles
-        for (int ct = 0; ct < tc; ct += TPS) {
+        for (int ct = g0 * TPS; ct < g1 * TPS; ct += TPS) {
             double e[TPS][4];
 #pragma unroll
             for (int tt = 0; tt < TPS; tt++) {
