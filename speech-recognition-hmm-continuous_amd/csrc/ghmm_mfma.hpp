@@ -444,6 +444,18 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
+        // the A fragments of this frame tile (x' and x'^2 of frame l & 15, k = 4s + (l >> 4))
+        // stay in registers for all of its Gaussian tiles where the epilogue leaves room
+        // (128 VGPRs = 4 waves per SIMD); otherwise they are re-read from the slab per tile
+        constexpr bool AREG = OUT != 2 && TPS == 1;
+        double a1[AREG ? Q : 1], a2[AREG ? Q : 1];
+        if (AREG) {
+#pragma unroll
+            for (int s = 0; s < Q; s++) {
+                a1[s] = xr[4 * s];
+                a2[s] = a1[s] * a1[s];
+            }
+        }
         // a state's mixtures fill MPL adjacent lanes of TPS consecutive tiles
         for (int ct = g0 * TPS; ct < g1 * TPS; ct += TPS) {
             double e[TPS][4];
@@ -451,11 +463,19 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
             for (int tt = 0; tt < TPS; tt++) {
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
                 const double *Wt = Wl + (size_t)(ct + tt) * KS * 64 + l;
+                if (AREG) {
+#pragma unroll
+                    for (int s = 0; s < Q; s++) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[AREG ? s : 0], Wt[s * 64], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[AREG ? s : 0], Wt[(Q + s) * 64], acc, 0, 0, 0);
+                    }
+                } else {
 #pragma unroll 5
-                for (int s = 0; s < Q; s++) {
-                    const double a1 = xr[4 * s];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Wt[s * 64], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * a1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                    for (int s = 0; s < Q; s++) {
+                        const double x1 = xr[4 * s];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, Wt[s * 64], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1 * x1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                    }
                 }
                 const double wkj = wkl[(ct + tt) * 16 + j];
                 if (OUT == 2) {
