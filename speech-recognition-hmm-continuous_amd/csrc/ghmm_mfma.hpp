@@ -664,7 +664,8 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                 const double *__restrict__ oglob, double *__restrict__ part)
 {
     extern __shared__ double lds[]; // fold: [CT*NE*4][64]; STAGED: per-wave frame stages
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index, in a scalar register
     const int G = N * M, ES = NE * 16;
     const int c0 = STAGED ? gmin / 16 : blockIdx.y * CT; // staged: one launch per chunk
     int gmA[CT], stA[CT];
@@ -800,20 +801,49 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                 if (l + 64 * u < ngp) ((v2d *)gs)[l + 64 * u] = rg[u];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
             fetch(stg + 1 < s1 ? stg + 1 : stg); // in flight under this stage's MFMAs
-#pragma unroll 1
-            for (int q = 0; q < 4; q++) {
-                const int r = 4 * q + kq;
-                double wv[CT], ft[NE];
+            // four k-steps per stage, two per iteration of a rolled loop (unrolling all four
+            // makes hipcc shuffle the accumulators between AGPRs and VGPRs).  Two operand
+            // sets alternate: the operands of the next step are read from LDS before the
+            // MFMAs of the current one are issued, since a lone wave has nothing else to hide
+            // the LDS latency with.
+            double gA[CT], pA[CT], fA[NE], gB[CT], pB[CT], fB[NE];
+            const double *gsl[CT], *psl[CT];
 #pragma unroll
-                for (int c = 0; c < CT; c++)
-                    wv[c] = gs[r * N + stA[c]] * ps[r * GW + (gmC[c] - gmin)] * mk[c];
+            for (int c = 0; c < CT; c++) {
+                gsl[c] = gs + kq * N + stA[c];
+                psl[c] = ps + kq * GW + (gmC[c] - gmin);
+            }
+            const double *fxl = fx + kq * XS + j;
+            auto rd = [&](int q, double (&g)[CT], double (&p)[CT], double (&f)[NE]) {
+                const int og = 4 * q * N, op = 4 * q * GW, of = 4 * q * XS; // wave-uniform
 #pragma unroll
-                for (int n = 0; n < NE; n++) ft[n] = fx[r * XS + 16 * n + j];
+                for (int c = 0; c < CT; c++) {
+                    g[c] = gsl[c][og];
+                    p[c] = psl[c][op];
+                }
+#pragma unroll
+                for (int n = 0; n < NE; n++) f[n] = fxl[of + 16 * n];
+            };
+            auto run = [&](const double (&g)[CT], const double (&p)[CT], const double (&f)[NE]) {
+                double wv[CT];
+#pragma unroll
+                for (int c = 0; c < CT; c++) wv[c] = g[c] * p[c] * mk[c];
 #pragma unroll
                 for (int c = 0; c < CT; c++)
 #pragma unroll
                     for (int n = 0; n < NE; n++)
-                        acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], ft[n], acc[c][n], 0, 0, 0);
+                        acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], f[n], acc[c][n], 0, 0, 0);
+            };
+            rd(0, gA, pA, fA);
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                __builtin_amdgcn_sched_barrier(0);
+                rd(2 * h + 1, gB, pB, fB);
+                run(gA, pA, fA);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(h == 0 ? 2 : 3, gA, pA, fA); // the last read is a repeat, unused
+                run(gB, pB, fB);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads(); // the stages alias the fold buffer below
