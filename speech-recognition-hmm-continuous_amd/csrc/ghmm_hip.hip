@@ -902,7 +902,8 @@ extern "C" int ghmm_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
 template <int CT, int NE>
 static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int P, int chunks)
 {
-    const size_t fold = (size_t)CT * NE * 4 * 64 * sizeof(double);
+    // fold buffer: four waves x half of the tiles (ghmm_mfma.hpp, end of k_mixstats_mfma)
+    const size_t fold = (size_t)MSM_WAVES * ((CT * NE + 1) / 2) * 4 * 64 * sizeof(double);
     // staged variant: every chunk of CT tiles must map to an even-aligned, even-length run of
     // real Gaussians (true when no mixture padding: Mp == M, M even) and N <= 16
     const int G = m->N * m->M;
@@ -930,6 +931,12 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
             }
             return GHMM_OK;
         }
+    }
+    static bool attr_ns = false;
+    if (!attr_ns) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_mixstats_mfma<CT, NE, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_ns = true;
     }
     hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, false>), dim3((unsigned)P, (unsigned)chunks),
                        dim3(MSM_WAVES * WAVE), fold, ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT,

@@ -647,6 +647,22 @@ __device__ inline long long uniform64(long long v)
     return ((long long)hi << 32) | (unsigned)lo;
 }
 
+// e / d and e % d for small non-negative e (< 2^20) without the ~40-instruction integer
+// division: float reciprocal, then one correction either way
+__device__ inline void divmod_small(int e, int d, float rd, int &q, int &r)
+{
+    q = (int)((float)e * rd);
+    r = e - q * d;
+    if (r < 0) {
+        r += d;
+        q--;
+    }
+    if (r >= d) {
+        r -= d;
+        q++;
+    }
+}
+
 constexpr int MSM_WAVES = 4;
 constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
@@ -737,29 +753,43 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         const int SZ = 16 * (XS + GW + N) + DP;
         double *fx = lds + (size_t)w * SZ, *ps = fx + 16 * XS, *gs = ps + 16 * GW, *ol = gs + 16 * N;
         for (int k = l; k < DP; k += WAVE) ol[k] = k < D ? oglob[k] : 0.0;
-        for (int k = l; k < 16 * XS; k += WAVE) { // constant columns: the 1 and the zeros
-            const int col = k % XS;
-            fx[k] = col == D ? 1.0 : 0.0;
-        }
+        for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
+            for (int col = l; col < XS; col += WAVE) fx[r * XS + col] = col == D ? 1.0 : 0.0;
         // 16-byte pieces moved per stage: X 8*D, posteriors 8*GW, gamma 8*N; lane l takes
-        // pieces l + 64u.  Bounds: 8*D <= 64*NE, 8*GW <= 64*2*CT, 8*N <= 64*2.
+        // pieces l + 64u.  Bounds: 8*D <= 64*NE, 8*GW <= 64*2*CT, 8*N <= 64*2.  Surplus lanes
+        // repeat the last piece, load and store alike (same value to the same place): no
+        // predicates, no branches in the stage writer.
         constexpr int NXL = NE, NPL = 2 * CT, NGL = 2;
         const int nxp = 8 * D, npp = 8 * GW, ngp = 8 * N, ppr = GW / 2;
+        const float rD = 1.0f / (float)D, rppr = 1.0f / (float)ppr;
         v2d rx[NXL], rp[NPL], rg[NGL];
         unsigned offp[NPL]; // posterior piece -> element offset inside a stage (rows strided by G)
+        unsigned pcp[NPL], pcx[NXL], pcg[NGL]; // clamped piece indices
 #pragma unroll
         for (int u = 0; u < NPL; u++) {
             int pc = l + 64 * u;
-            pc = pc < npp ? pc : npp - 1; // surplus lanes re-read the last piece
-            const int row = pc / ppr, c2 = pc - row * ppr;
+            pc = pc < npp ? pc : npp - 1;
+            pcp[u] = (unsigned)pc;
+            int row, c2;
+            divmod_small(pc, ppr, rppr, row, c2);
             offp[u] = (unsigned)(row * G + gmin + 2 * c2);
+        }
+#pragma unroll
+        for (int u = 0; u < NGL; u++) {
+            const int pc = l + 64 * u;
+            pcg[u] = (unsigned)(pc < ngp ? pc : ngp - 1);
         }
         // where the two doubles of X piece u land: (slab offset << 8) | coefficient index
         unsigned xa[NXL], xb[NXL];
 #pragma unroll
         for (int u = 0; u < NXL; u++) {
-            const int e0 = 2 * (l + 64 * u), e1 = e0 + 1;
-            const int r0 = e0 / D, d0 = e0 - r0 * D, r1 = e1 / D, d1 = e1 - r1 * D;
+            int pc = l + 64 * u;
+            pc = pc < nxp ? pc : nxp - 1;
+            pcx[u] = (unsigned)pc;
+            const int e0 = 2 * pc;
+            int r0, d0;
+            divmod_small(e0, D, rD, r0, d0);
+            const int r1 = d0 + 1 < D ? r0 : r0 + 1, d1 = d0 + 1 < D ? d0 + 1 : 0;
             xa[u] = ((unsigned)(r0 * XS + d0) << 8) | (unsigned)d0;
             xb[u] = ((unsigned)(r1 * XS + d1) << 8) | (unsigned)d1;
         }
@@ -769,36 +799,27 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             const v2d *gsrc = (const v2d *)(gamma + uniform64(f * N));
             const double *psrc = post + uniform64(f * G);
 #pragma unroll
-            for (int u = 0; u < NXL; u++) {
-                int pc = l + 64 * u;
-                rx[u] = xsrc[pc < nxp ? pc : nxp - 1];
-            }
+            for (int u = 0; u < NXL; u++) rx[u] = xsrc[pcx[u]];
 #pragma unroll
             for (int u = 0; u < NPL; u++) rp[u] = *(const v2d *)(psrc + offp[u]);
 #pragma unroll
-            for (int u = 0; u < NGL; u++) {
-                int pc = l + 64 * u;
-                rg[u] = gsrc[pc < ngp ? pc : ngp - 1];
-            }
+            for (int u = 0; u < NGL; u++) rg[u] = gsrc[pcg[u]];
         };
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (s0 < s1) fetch(s0);
         for (long long stg = s0; stg < s1; stg++) {
 #pragma unroll
-            for (int u = 0; u < NXL; u++)
-                if (l + 64 * u < nxp) {
-                    const double x0 = rx[u][0] - ol[xa[u] & 255u], x1 = rx[u][1] - ol[xb[u] & 255u];
-                    fx[xa[u] >> 8] = x0;
-                    fx[(xa[u] >> 8) + DP] = x0 * x0;
-                    fx[xb[u] >> 8] = x1;
-                    fx[(xb[u] >> 8) + DP] = x1 * x1;
-                }
+            for (int u = 0; u < NXL; u++) {
+                const double x0 = rx[u][0] - ol[xa[u] & 255u], x1 = rx[u][1] - ol[xb[u] & 255u];
+                fx[xa[u] >> 8] = x0;
+                fx[(xa[u] >> 8) + DP] = x0 * x0;
+                fx[xb[u] >> 8] = x1;
+                fx[(xb[u] >> 8) + DP] = x1 * x1;
+            }
 #pragma unroll
-            for (int u = 0; u < NPL; u++)
-                if (l + 64 * u < npp) ((v2d *)ps)[l + 64 * u] = rp[u];
+            for (int u = 0; u < NPL; u++) ((v2d *)ps)[pcp[u]] = rp[u];
 #pragma unroll
-            for (int u = 0; u < NGL; u++)
-                if (l + 64 * u < ngp) ((v2d *)gs)[l + 64 * u] = rg[u];
+            for (int u = 0; u < NGL; u++) ((v2d *)gs)[pcg[u]] = rg[u];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
             fetch(stg + 1 < s1 ? stg + 1 : stg); // in flight under this stage's MFMAs
             // four k-steps per stage, two per iteration of a rolled loop (unrolling all four
@@ -916,27 +937,34 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             }
         }
     }
-    // fold the block's waves in wave order, then write the block's partial
-    for (int ww = 0; ww < MSM_WAVES; ww++) {
-        if (w == ww) {
+    // Fold the block's waves in wave order and write the block's partial, all four waves at
+    // work: in two rounds of half the tiles, every wave parks its tiles in LDS, then each wave
+    // adds up (wave 0 + wave 1 + wave 2 + wave 3, in that order) a quarter of the round's
+    // tile rows and stores them.
+    constexpr int TILES = CT * NE, TPR = (TILES + 1) / 2; // tiles per round
 #pragma unroll
-            for (int c = 0; c < CT; c++)
-#pragma unroll
-                for (int n = 0; n < NE; n++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int li = ((c * NE + n) * 4 + r) * 64 + l;
-                        if (ww == 0) lds[li] = acc[c][n][r];
-                        else if (ww < MSM_WAVES - 1) lds[li] += acc[c][n][r];
-                        else {
-                            const int gp = (c0 + c) * 16 + kq + 4 * r;
-                            if (c0 + c < NT)
-                                part[((size_t)blockIdx.x * NT * 16 + gp) * ES + 16 * n + j] =
-                                    lds[li] + acc[c][n][r];
-                        }
-                    }
-        }
+    for (int rnd = 0; rnd < 2; rnd++) {
         __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CT; c++)
+#pragma unroll
+            for (int n = 0; n < NE; n++) {
+                const int tl = c * NE + n - rnd * TPR; // tile index inside this round
+                if (tl >= 0 && tl < TPR) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) lds[((size_t)(w * TPR + tl) * 4 + r) * 64 + l] = acc[c][n][r];
+                }
+            }
+        __syncthreads();
+        const int nt = (TILES - rnd * TPR) < TPR ? (TILES - rnd * TPR) : TPR;
+        for (int q = w; q < nt * 4; q += MSM_WAVES) { // q = (tile, register row)
+            const int tl = q >> 2, r = q & 3, t = tl + rnd * TPR, c = t / NE, n = t - c * NE;
+            double v = lds[((size_t)(0 * TPR + tl) * 4 + r) * 64 + l];
+#pragma unroll
+            for (int ww = 1; ww < MSM_WAVES; ww++) v += lds[((size_t)(ww * TPR + tl) * 4 + r) * 64 + l];
+            const int gp = (c0 + c) * 16 + kq + 4 * r;
+            if (c0 + c < NT) part[((size_t)blockIdx.x * NT * 16 + gp) * ES + 16 * n + j] = v;
+        }
     }
 }
 
