@@ -81,6 +81,7 @@ struct ghmm_model {
     double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *logwkp = nullptr, *condp = nullptr;
     double *oglob = nullptr, *condg = nullptr;
     int *gmap = nullptr, *anyflag = nullptr;
+    int epoch = 0; // preparation count; anyflag[0] == epoch: this model holds an ill-conditioned Gaussian
     int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
 };
 
@@ -341,13 +342,13 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
     if ((rc = launch_ok("k_prepare")) || !m->mfma_ok) return rc;
     {
         kscope ks(ctx, GHMM_K_PREPARE);
+        m->epoch++;
         hipLaunchKernelGGL(k_prepare_offsets, dim3((unsigned)(m->NT + m->D)), dim3(64), 0, ctx->stream,
-                           m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob,
-                           m->anyflag);
+                           m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob);
         hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)(m->NT * 16)), dim3(64), 0,
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
                            m->wk, m->logwk, m->offs, m->oglob, m->Wm, m->wkp, m->logwkp, m->gmap,
-                           m->condp, m->condg, m->anyflag);
+                           m->condp, m->condg, m->anyflag, m->epoch);
     }
     return launch_ok("k_prepare_mfma");
 }
@@ -716,7 +717,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         hipLaunchKernelGGL((k_emission_sched<20, MP, 2>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,  \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->logwkp, m->gmap, ctx->b,       \
-                           (double *)nullptr, ctx->sink, m->anyflag);                             \
+                           (double *)nullptr, ctx->sink, m->anyflag, m->epoch);                   \
     } while (0)
         switch (m->Mp) {
         case 1: GHMM_EML(1, 0); break;
@@ -763,7 +764,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,   \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap, ctx->b, post,     \
-                           ctx->sink, m->anyflag);                                                \
+                           ctx->sink, m->anyflag, m->epoch);                                      \
     } while (0)
 #define GHMM_EMS2(MP)                                                                             \
     do {                                                                                          \
@@ -784,7 +785,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
                                dim3(EM_WAVES * WAVE), m->em_lds, ctx->stream, m->N, m->M, m->Mp, m->D,
                                m->DP, m->NT, m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap,
                                m->condg, m->mean, m->inv_var, ctx->b, post,
-                               sched ? m->anyflag : (const int *)nullptr);
+                               sched ? m->anyflag : (const int *)nullptr, m->epoch);
         }
         ctx->b_is_log = false;
         return launch_ok("k_emission_mfma");
@@ -795,15 +796,15 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         if (mode == 0)
             hipLaunchKernelGGL(k_emission<0>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
                                m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
-                               ctx->b, post, ctx->lognorm, only_if);
+                               ctx->b, post, ctx->lognorm, only_if, m->epoch);
         else if (mode == 1)
             hipLaunchKernelGGL(k_emission<1>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
                                m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
-                               ctx->b, post, ctx->lognorm, only_if);
+                               ctx->b, post, ctx->lognorm, only_if, m->epoch);
         else
             hipLaunchKernelGGL(k_emission<2>, dim3((unsigned)blocks), dim3(WAVE), lds, ctx->stream,
                                m->N, m->M, m->D, c->F, c->X, m->mean, m->inv_var, m->wk, m->logwk,
-                               ctx->b, post, ctx->lognorm, only_if);
+                               ctx->b, post, ctx->lognorm, only_if, m->epoch);
     }
     ctx->b_is_log = (mode == 2);
     return launch_ok("k_emission");
@@ -1008,7 +1009,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         kscope ks(ctx, GHMM_K_MIXSTATS);
         hipLaunchKernelGGL(k_mixstats, dim3((unsigned)P, (unsigned)NB), dim3(MS_THREADS), lds,
                            ctx->stream, N, M, D, c->F, fpb, FS, c->X, ctx->gamma, ctx->post, m->mean,
-                           ctx->part_mu, ctx->part_var, only_if);
+                           ctx->part_mu, ctx->part_var, only_if, m->epoch);
         if ((rc = launch_ok("k_mixstats"))) return rc;
     }
     {
@@ -1103,7 +1104,17 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
     {
         kscope ks(ctx, GHMM_K_MSTEP);
         size_t md = (size_t)m->M * m->D;
-        int lds_doubles = md * 8 <= 60 * 1024 ? (int)md : 0;
+        int lds_doubles = md * 8 <= 56 * 1024 ? (int)md : 0; // + offsets and a reduction buffer: under 64 KB
+        if (m->mfma_ok) {
+            // M-step and matrix-core preparation of the new model in one launch
+            m->epoch++;
+            hipLaunchKernelGGL(k_mstep_mfma, dim3((unsigned)m->N), dim3(MSF_THREADS),
+                               ((size_t)lds_doubles + m->DP + MSF_THREADS) * 8, ctx->stream, m->N, m->M, m->D, s->v,
+                               pow(2.0 * M_PI, m->D / 2.0), m->A, m->c, m->mean, m->inv_var, m->det, m->wk,
+                               m->logwk, m->logA, lds_doubles, m->Mp, m->NT, m->DP, m->oglob, m->Wm, m->wkp,
+                               m->logwkp, m->gmap, m->condg, m->anyflag, m->epoch);
+            return launch_ok("k_mstep_mfma");
+        }
         hipLaunchKernelGGL(k_mstep, dim3((unsigned)m->N), dim3(MS2_THREADS), (size_t)lds_doubles * 8,
                            ctx->stream, m->N, m->M, m->D, s->v, pow(2.0 * M_PI, m->D / 2.0), m->A, m->c,
                            m->mean, m->inv_var, m->det, m->wk, m->logwk, m->logA, lds_doubles);

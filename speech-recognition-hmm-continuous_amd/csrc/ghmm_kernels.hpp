@@ -51,10 +51,11 @@ k_emission(int N, int M, int D, long long F, const double *__restrict__ X,
            const double *__restrict__ mean, const double *__restrict__ inv_var,
            const double *__restrict__ wk, const double *__restrict__ logwk,
            double *__restrict__ b, double *__restrict__ post, double *__restrict__ lognorm,
-           const int *__restrict__ only_if)
+           const int *__restrict__ only_if, int epoch)
 {
     extern __shared__ double lds[];
-    if (only_if && only_if[0] == 0) return; // the matrix-core kernel has done the job
+    // only_if[0] == epoch: the model's current preparation found an ill-conditioned Gaussian
+    if (only_if && only_if[0] != epoch) return; // the matrix-core kernel has done the job
     const int DS = D | 1;
     const int lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * WAVE;
@@ -673,10 +674,10 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
            const double *__restrict__ X, const double *__restrict__ gamma,
            const double *__restrict__ post, const double *__restrict__ mean,
            double *__restrict__ part_mu, double *__restrict__ part_var,
-           const int *__restrict__ only_if)
+           const int *__restrict__ only_if, int epoch)
 {
     extern __shared__ double lds[];
-    if (only_if && only_if[0] == 0) return; // matrix-core tier: nothing is ill-conditioned
+    if (only_if && only_if[0] != epoch) return; // matrix-core tier: nothing is ill-conditioned
     const int G = N * M, D1 = D + 1;
     const long long E = (long long)G * D1;
     const int tid = threadIdx.x;
@@ -886,16 +887,16 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
 // det/inverse as if they were variances) — and the derived constants of k_prepare.
 // One block per state.
 constexpr int MS2_THREADS = 128;
-__global__ void __launch_bounds__(MS2_THREADS)
-k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
-        double *__restrict__ A, double *__restrict__ c, double *__restrict__ mean,
-        double *__restrict__ inv_var, double *__restrict__ det, double *__restrict__ wk,
-        double *__restrict__ logwk, double *__restrict__ logA, int lds_doubles)
+__device__ inline void mstep_state(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
+                                   double *__restrict__ A, double *__restrict__ c, double *__restrict__ mean,
+                                   double *__restrict__ inv_var, double *__restrict__ det,
+                                   double *__restrict__ wk, double *__restrict__ logwk,
+                                   double *__restrict__ logA, int lds_doubles, double *vs)
 {
-    const int G = N * M, i = blockIdx.x, tid = threadIdx.x;
+    const int G = N * M, i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const double *num_a = stats, *den_a = num_a + (size_t)N * N, *den_c = den_a + N;
     const double *num_c = den_c + N, *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
-    for (int j = tid; j < N; j += MS2_THREADS) {
+    for (int j = tid; j < N; j += nt) {
         double v = A[i * N + j];
         if (den_a[i] != 0.0) {
             v = num_a[i * N + j] / den_a[i];
@@ -904,7 +905,7 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
         logA[i * N + j] = v > 0.0 ? log(v) : -INFINITY;
     }
     if (den_c[i] != 0.0) {
-        for (int k = tid; k < M * D; k += MS2_THREADS) {
+        for (int k = tid; k < M * D; k += nt) {
             const int g = i * M + k / D;
             const size_t q = (size_t)i * M * D + k;
             mean[q] = num_mu[q] / num_c[g];
@@ -912,7 +913,7 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
             if (v < FLOOR) v = FLOOR;
             inv_var[q] = v;
         }
-        for (int m = tid; m < M; m += MS2_THREADS) c[i * M + m] = num_c[i * M + m] / den_c[i];
+        for (int m = tid; m < M; m += nt) c[i * M + m] = num_c[i * M + m] / den_c[i];
     }
     __syncthreads();
     if (tid == 0) {
@@ -929,15 +930,14 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
     // det = product of the (floored) variances in order, then the inverses (TF:343-346);
     // the state's M*D values go through LDS so that the serial product does not pay a
     // global-memory round trip per factor
-    extern __shared__ double vs[];
     const double *src = inv_var + (size_t)i * M * D;
     const bool staged = lds_doubles >= M * D;
     if (staged) {
-        for (int k = tid; k < M * D; k += MS2_THREADS) vs[k] = src[k];
+        for (int k = tid; k < M * D; k += nt) vs[k] = src[k];
         __syncthreads();
         src = vs;
     }
-    for (int m = tid; m < M; m += MS2_THREADS) {
+    for (int m = tid; m < M; m += nt) {
         const int g = i * M + m;
         const double *v = staged ? src + (size_t)m * D : inv_var + (size_t)g * D;
         double d = 1.0;
@@ -947,10 +947,20 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
         wk[g] = c[g] / den;
         logwk[g] = log(c[g]) - log(den);
     }
-    for (int k = tid; k < M * D; k += MS2_THREADS) {
+    for (int k = tid; k < M * D; k += nt) {
         const size_t q = (size_t)i * M * D + k;
         inv_var[q] = 1.0 / (staged ? vs[k] : inv_var[q]);
     }
+}
+
+__global__ void __launch_bounds__(MS2_THREADS)
+k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
+        double *__restrict__ A, double *__restrict__ c, double *__restrict__ mean,
+        double *__restrict__ inv_var, double *__restrict__ det, double *__restrict__ wk,
+        double *__restrict__ logwk, double *__restrict__ logA, int lds_doubles)
+{
+    extern __shared__ double vs[];
+    mstep_state(N, M, D, stats, norm2pi, A, c, mean, inv_var, det, wk, logwk, logA, lds_doubles, vs);
 }
 
 // --------------------------------------------------------------- init model

@@ -34,10 +34,9 @@ constexpr int EM_XR = 16;          // frame-tile doubles per lane: 16*D/64, D <=
 // Gaussians (0 beyond D); oglob[d] = mean of all means (grid = NT + D blocks).
 __global__ void __launch_bounds__(64)
 k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__restrict__ mean,
-                  double *__restrict__ offs, double *__restrict__ oglob, int *__restrict__ anyflag)
+                  double *__restrict__ offs, double *__restrict__ oglob)
 {
     const int q = blockIdx.x, t = threadIdx.x;
-    if (q == 0 && t == 0) anyflag[0] = 0; // k_prepare_mfma (next in the stream) raises it
     if (q < NT) {
         for (int d = t; d < DP; d += 64) {
             double o = 0.0;
@@ -80,7 +79,8 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
                const double *__restrict__ logwk, const double *__restrict__ offs,
                const double *__restrict__ oglob, double *__restrict__ Wm, double *__restrict__ wkp,
                double *__restrict__ logwkp, int *__restrict__ gmap,
-               double *__restrict__ condp, double *__restrict__ condg, int *__restrict__ anyflag)
+               double *__restrict__ condp, double *__restrict__ condg, int *__restrict__ anyflag,
+               int epoch)
 {
     __shared__ double sh0[64], sh1[64];
     const int gp = blockIdx.x, t = threadIdx.x;
@@ -124,7 +124,98 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
         condg[gp] = real ? cg : 0.0;
         // some Gaussian too ill-conditioned for the expanded forms: k_emission_mfma's direct
         // form and the vector-ALU k_mixstats then take over for it
-        if (real && cg > COND_MAX) atomicOr(anyflag, 1);
+        // (anyflag[0] == the model's preparation count means "flagged now": nothing has to
+        // clear it, every writer of one preparation stores the same value)
+        if (real && cg > COND_MAX) anyflag[0] = epoch;
+    }
+}
+
+// The M-step (k_mstep's arithmetic, unchanged) and the matrix-core preparation of the new
+// model in one launch: block = state.  After the state's parameters are final, each wave of
+// the block builds the B-fragment columns of the state's padded Gaussians exactly as
+// k_prepare_mfma does (the last block also fills the padding columns behind state N-1).
+// The offset of the expanded forms is the data's centre taken from the statistics themselves,
+// oglob_d = sum_g num_mu[g][d] / sum_g num_c[g], which every block computes for itself (same
+// sums in the same order): no kernel boundary is needed for it.
+constexpr int MSF_THREADS = 512; // one wave per padded Gaussian of an 8-mixture state
+__global__ void __launch_bounds__(MSF_THREADS)
+k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
+             double *__restrict__ A, double *__restrict__ c, double *__restrict__ mean,
+             double *__restrict__ inv_var, double *__restrict__ det, double *__restrict__ wk,
+             double *__restrict__ logwk, double *__restrict__ logA, int lds_doubles, int Mp, int NT,
+             int DP, double *__restrict__ oglob, double *__restrict__ Wm, double *__restrict__ wkp,
+             double *__restrict__ logwkp, int *__restrict__ gmap, double *__restrict__ condg,
+             int *__restrict__ anyflag, int epoch)
+{
+    extern __shared__ double vs[]; // [lds_doubles] staging of mstep_state | og[DP] | red[MSF_THREADS]
+    double *og = vs + lds_doubles, *red = og + DP;
+    const int G = N * M, i = blockIdx.x, tid = threadIdx.x, KS = DP / 2;
+    {
+        // thread (d, part) adds every np-th Gaussian of column d; parts are added in order
+        const double *num_c = stats + (size_t)N * N + 2 * (size_t)N, *num_mu = num_c + G;
+        const int np = MSF_THREADS / DP, d = tid % DP, part = tid / DP;
+        double o = 0.0, cn = 0.0;
+        if (part < np)
+            for (int g = part; g < G; g += np) {
+                cn += num_c[g];
+                if (d < D) o += num_mu[(size_t)g * D + d];
+            }
+        red[tid] = o;
+        __syncthreads();
+        if (tid < DP) {
+            double tot = 0.0;
+            for (int q = 0; q < np; q++) tot += red[q * DP + tid];
+            og[tid] = tot;
+        }
+        __syncthreads();
+        red[tid] = cn; // every column's threads hold the same partial counts: column 0's are used
+        __syncthreads();
+        if (tid < DP) {
+            double cnt = 0.0;
+            for (int q = 0; q < np; q++) cnt += red[q * DP];
+            double o2 = 0.0;
+            if (tid < D) {
+                o2 = (cnt > 0.0 && cnt < INFINITY) ? og[tid] / cnt : oglob[tid];
+                if (!(fabs(o2) < INFINITY)) o2 = 0.0;
+                if (i == 0) oglob[tid] = o2;
+            }
+            og[tid] = o2;
+        }
+        __syncthreads();
+    }
+    mstep_state(N, M, D, stats, norm2pi, A, c, mean, inv_var, det, wk, logwk, logA, lds_doubles, vs);
+    __syncthreads(); // the state's new parameters (global) and og (LDS) are visible to the block
+    const int w = tid >> 6, l = tid & 63;
+    const int gp0 = i * Mp, gp1 = (i == N - 1) ? NT * 16 : (i + 1) * Mp;
+    for (int gp = gp0 + w; gp < gp1; gp += MSF_THREADS / 64) {
+        const int ct = gp >> 4, j = gp & 15;
+        const int ii = gp / Mp, m = gp % Mp;
+        const bool real = (ii < N) && (m < M);
+        const int g = real ? ii * M + m : -1;
+        double *Wc = Wm + (size_t)ct * KS * 64;
+        double cg = 0.0;
+        for (int d = l; d < DP; d += 64) {
+            double bc = 0.0, ac = 0.0;
+            if (real && d < D) {
+                const double mu = mean[(size_t)g * D + d] - og[d], iv = inv_var[(size_t)g * D + d];
+                bc = mu * iv;
+                ac = -0.5 * iv;
+                cg += mu * mu * iv;
+            }
+            if (d != D) Wc[(d >> 2) * 64 + (d & 3) * 16 + j] = bc;
+            const int k2 = DP + d;
+            Wc[(k2 >> 2) * 64 + (k2 & 3) * 16 + j] = ac;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cg += __shfl_xor(cg, o, 64);
+        if (l == 0) {
+            gmap[gp] = g;
+            wkp[gp] = real ? wk[g] : 0.0;
+            logwkp[gp] = real ? logwk[g] : -1.0e300;
+            Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0;
+            condg[gp] = real ? cg : 0.0;
+            if (real && cg > COND_MAX) anyflag[0] = epoch;
+        }
     }
 }
 
@@ -143,10 +234,11 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                 const double *__restrict__ oglob, const double *__restrict__ wkp,
                 const int *__restrict__ gmap, const double *__restrict__ condg,
                 const double *__restrict__ mean, const double *__restrict__ inv_var,
-                double *__restrict__ b, double *__restrict__ post, const int *__restrict__ only_if)
+                double *__restrict__ b, double *__restrict__ post, const int *__restrict__ only_if,
+                int epoch)
 {
     extern __shared__ double lds[];
-    if (only_if && only_if[0] == 0) return; // k_emission_sched has done the job
+    if (only_if && only_if[0] != epoch) return; // k_emission_sched has done the job
     const int KS = DP / 2, XS = 2 * DP + 1, G = N * M;
     double *Wl = lds;                                // [TC][KS][64]
     double *xl = Wl + (size_t)TC * KS * 64;          // [EM_WAVES][16][XS]
@@ -360,10 +452,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                  const double *__restrict__ Wm, const double *__restrict__ oglob,
                  const double *__restrict__ wkp, const int *__restrict__ gmap,
                  double *__restrict__ b, double *__restrict__ post, double *__restrict__ sink,
-                 const int *__restrict__ anyflag)
+                 const int *__restrict__ anyflag, int epoch)
 {
     extern __shared__ double lds[];
-    if (anyflag[0]) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
+    if (anyflag[0] == epoch) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
     constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 1;
     constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : MP == 16 ? 4 : MP == 32 ? 5 : 6;
     constexpr int MPL = MP < 16 ? MP : 16, TPS = MP <= 16 ? 1 : MP / 16;
