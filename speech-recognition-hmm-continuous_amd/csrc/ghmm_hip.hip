@@ -16,6 +16,7 @@
 
 #include "ghmm_kernels.hpp"
 #include "ghmm_mfma.hpp"
+#include "ghmm_pair.hpp"
 
 extern "C" void ghmm_set_error(const char *fmt, ...); // ghmm_io.c
 
@@ -60,6 +61,16 @@ struct ghmm_ctx {
     double *scale = nullptr, *sinv = nullptr, *lognorm = nullptr, *loglik = nullptr;
     double *sink = nullptr; // [0,64): idle lanes' stores land here; [64,128): zeros they read
     double *part_xi = nullptr, *part_dena = nullptr, *part_denc = nullptr;
+    // paired scans (ghmm_pair.hpp): W rows and 1/s_t of the backward pass with its own normaliser
+    double *wrow = nullptr, *sb = nullptr;
+    size_t cap_wrow = 0, cap_sb = 0;
+    bool own_bwd_done = false; // k_scan_pair ran the backward direction for the current alpha
+    bool beta_valid = false;   // ctx->beta holds the reference's beta^
+    // what the last gamma / xi pass ran on, so that ghmm_fetch(GHMM_BUF_BETA) can form beta^ when
+    // ghmm_estep skipped it; cleared when that model changes or either object goes away
+    ghmm_model *last_m = nullptr;
+    ghmm_corpus *last_c = nullptr;
+    int slots = 0;             // partial-sum slots filled by the last backward / combine pass
     double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr;
     unsigned char *psi = nullptr;
     int *path = nullptr;
@@ -224,7 +235,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     void *bufs[] = {ctx->b,       ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
-                    ctx->part_m,  ctx->sinv,      ctx->sink};
+                    ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &t : ctx->kt) {
@@ -414,6 +425,7 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
 extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
 {
     if (!m) return;
+    if (ctx && ctx->last_m == m) ctx->last_m = nullptr;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
@@ -430,6 +442,7 @@ extern "C" int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, con
                               const double *mean, const double *inv_var, const double *det)
 {
     int rc = use(ctx);
+    if (ctx && ctx->last_m == m) ctx->last_m = nullptr; // alpha^ / W on the device belong to the old parameters
     if (rc) return rc;
     ARG_CHECK(m && A && c && mean && inv_var && det, "null argument");
     size_t G = (size_t)m->N * m->M, NN = (size_t)m->N * m->N;
@@ -540,6 +553,7 @@ extern "C" int ghmm_corpus_wrap(ghmm_ctx *ctx, const double *X_dev, const int32_
 extern "C" void ghmm_corpus_destroy(ghmm_ctx *ctx, ghmm_corpus *c)
 {
     if (!c) return;
+    if (ctx && ctx->last_c == c) ctx->last_c = nullptr;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
@@ -656,8 +670,8 @@ static int ws_frames(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c, b
     if ((rc = dev_grow(&ctx->scale, &ctx->cap_scale, F))) return rc;
     if ((rc = dev_grow(&ctx->sinv, &ctx->cap_sinv, F))) return rc;
     if (!ctx->sink) {
-        if ((rc = dev_grow(&ctx->sink, &ctx->cap_sink, (size_t)2 * WAVE))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->sink, 0, 2 * WAVE * sizeof(double), ctx->stream));
+        if ((rc = dev_grow(&ctx->sink, &ctx->cap_sink, (size_t)2 * WAVE * SINK_WAVES))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->sink, 0, (size_t)2 * WAVE * SINK_WAVES * sizeof(double), ctx->stream));
     }
     if ((rc = dev_grow(&ctx->lognorm, &ctx->cap_lognorm, F))) return rc;
     if ((rc = dev_grow(&ctx->loglik, &ctx->cap_loglik, (size_t)c->U))) return rc;
@@ -671,7 +685,9 @@ static int ws_frames(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c, b
 static int ws_fb(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
 {
     int rc;
-    size_t FN = (size_t)c->F * m->N, UN = (size_t)c->U * m->N;
+    size_t FN = (size_t)c->F * m->N, UN = (size_t)c->U * m->N * CB_CH; // one slot per (utterance, chunk)
+    if ((rc = dev_grow(&ctx->wrow, &ctx->cap_wrow, FN))) return rc;
+    if ((rc = dev_grow(&ctx->sb, &ctx->cap_sb, (size_t)c->F))) return rc;
     if ((rc = dev_grow(&ctx->alpha, &ctx->cap_alpha, FN))) return rc;
     if ((rc = dev_grow(&ctx->beta, &ctx->cap_beta, FN))) return rc;
     if ((rc = dev_grow(&ctx->gamma, &ctx->cap_gamma, FN))) return rc;
@@ -832,7 +848,11 @@ static int fb_lanes(const ghmm_model *m, int *L)
     return GHMM_OK;
 }
 
-static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+// The paired scans of ghmm_pair.hpp unless GHMM_OPT_KERNELS = 1 asks for the reference's order
+// (calc_alpha, then calc_beta scaled by its c_t) in the one-pass kernels.
+static bool use_pair(const ghmm_ctx *ctx) { return ctx->kernels != 1; }
+
+static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_backward = false)
 {
     if (c->U == 0) return GHMM_OK;
     int L, rc;
@@ -840,9 +860,23 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
     const int gpw = WAVE / L;
     const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
     const double *ln = ctx->robust ? ctx->lognorm : nullptr;
+    ctx->own_bwd_done = false;
+    ctx->beta_valid = false;
     {
         kscope ks(ctx, GHMM_K_FORWARD);
-        if (L == 16)
+        if (use_pair(ctx)) {
+            const unsigned ny = with_backward ? 2u : 1u;
+            const int only = with_backward ? -1 : 0;
+            if (L == 16)
+                hipLaunchKernelGGL(k_scan_pair<16>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                   only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
+                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+            else
+                hipLaunchKernelGGL(k_scan_pair<64>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                   only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
+                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+            ctx->own_bwd_done = with_backward;
+        } else if (L == 16)
             hipLaunchKernelGGL(k_forward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink);
         else
@@ -852,23 +886,59 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
     return launch_ok("k_forward");
 }
 
-static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+// gamma, the xi / den partial sums and (want_beta) the reference's beta^
+static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_beta = true)
 {
-    if (c->U == 0) return GHMM_OK;
+    if (c->U == 0) {
+        ctx->slots = 0; // nothing was accumulated: every utterance sum is empty
+        return GHMM_OK;
+    }
     int L, rc;
     if ((rc = fb_lanes(m, &L))) return rc;
     const int gpw = WAVE / L;
     const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
     {
         kscope ks(ctx, GHMM_K_BACKWARD);
-        if (L == 16)
-            hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
-        else
-            hipLaunchKernelGGL(k_backward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                               ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
+        if (use_pair(ctx)) {
+            if (!ctx->own_bwd_done) { // the forward pass ran alone (row API): the other direction now
+                if (L == 16)
+                    hipLaunchKernelGGL(k_scan_pair<16>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream, m->N,
+                                       c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
+                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+                else
+                    hipLaunchKernelGGL(k_scan_pair<64>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream, m->N,
+                                       c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
+                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+                ctx->own_bwd_done = true;
+            }
+            const unsigned cb = (unsigned)(((long long)c->U * CB_CH + gpw - 1) / gpw);
+#define GHMM_COMBINE(LL, WB)                                                                       \
+    hipLaunchKernelGGL((k_combine<LL, WB>), dim3(cb), dim3(WAVE), 0, ctx->stream, m->N, c->U,      \
+                       (int)ctx->delta, m->A, c->off, ctx->alpha, ctx->scale, ctx->wrow, ctx->sb, \
+                       ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink)
+            if (L == 16) {
+                if (want_beta) GHMM_COMBINE(16, true);
+                else GHMM_COMBINE(16, false);
+            } else {
+                if (want_beta) GHMM_COMBINE(64, true);
+                else GHMM_COMBINE(64, false);
+            }
+            ctx->beta_valid = want_beta;
+            ctx->last_m = m;
+            ctx->last_c = c;
+            ctx->slots = c->U * CB_CH;
+        } else {
+            if (L == 16)
+                hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                   (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
+                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
+            else
+                hipLaunchKernelGGL(k_backward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                   (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
+                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
+            ctx->beta_valid = true;
+            ctx->slots = c->U;
+        }
     }
     return launch_ok("k_backward");
 }
@@ -1015,6 +1085,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     {
         reduce_args ra;
         ra.N = N; ra.M = M; ra.D = D; ra.U = c->U; ra.delta = (int)ctx->delta;
+        ra.S = ctx->slots;
         ra.P1 = (int)P; ra.part_mu = ctx->part_mu; ra.part_var = ctx->part_var;
         ra.Pm = (mfma && c->F > 0) ? Pm : 0;
         ra.NT = m->NT; ra.DP = m->DP; ra.ES = m->NE * 16;
@@ -1064,7 +1135,18 @@ extern "C" int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n)
     case GHMM_BUF_B: src = ctx->b; have = F * N; break;
     case GHMM_BUF_POST: src = ctx->post; have = F * G; break;
     case GHMM_BUF_ALPHA: src = ctx->alpha; have = F * N; break;
-    case GHMM_BUF_BETA: src = ctx->beta; have = F * N; break;
+    case GHMM_BUF_BETA:
+        if (!ctx->beta_valid && ctx->beta) {
+            // ghmm_estep leaves beta^ out; form it now from the same alpha^, W and 1/s
+            if (!ctx->last_m || !ctx->last_c) {
+                ghmm_set_error("beta^ of the last E-step is gone (the model changed): call ghmm_backward");
+                return GHMM_ERR_ARG;
+            }
+            if ((rc = run_backward(ctx, ctx->last_m, ctx->last_c, true))) return rc;
+        }
+        src = ctx->beta;
+        have = F * N;
+        break;
     case GHMM_BUF_SCALE: src = ctx->scale; have = F; break;
     case GHMM_BUF_GAMMA: src = ctx->gamma; have = F * N; break;
     case GHMM_BUF_LOGLIK: src = ctx->loglik; have = U; break;
@@ -1090,14 +1172,15 @@ extern "C" int ghmm_estep(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     if (rc || (rc = check_pair(m, c)) || (rc = check_stats(m, s))) return rc;
     if ((rc = ws_frames(ctx, m, c, true)) || (rc = ws_fb(ctx, m, c))) return rc;
     if ((rc = run_emission(ctx, m, c, ctx->robust ? 1 : 0, true))) return rc;
-    if ((rc = run_forward(ctx, m, c))) return rc;
-    if ((rc = run_backward(ctx, m, c))) return rc;
+    if ((rc = run_forward(ctx, m, c, true))) return rc;
+    if ((rc = run_backward(ctx, m, c, false))) return rc; // beta^ on demand (ghmm_fetch)
     return run_accumulate(ctx, m, c, s);
 }
 
 extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
 {
     int rc = use(ctx);
+    if (ctx && ctx->last_m == m) ctx->last_m = nullptr; // alpha^ / W on the device belong to the old parameters
     if (rc) return rc;
     ARG_CHECK(m, "null model");
     if ((rc = check_stats(m, s))) return rc;
@@ -1137,6 +1220,7 @@ extern "C" int ghmm_model_init(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
     HIP_TRY(hipMemsetAsync(ctx->part_xi, 0, (size_t)c->U * N * (MAX_DELTA + 1) * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->part_dena, 0, (size_t)c->U * N * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->part_denc, 0, (size_t)c->U * N * 8, ctx->stream));
+    ctx->slots = c->U;
     HIP_TRY(hipMemsetAsync(ctx->loglik, 0, (size_t)c->U * 8, ctx->stream));
     ghmm_stats *st = nullptr;
     if ((rc = ghmm_stats_create(ctx, N, M, D, &st))) return rc;

@@ -257,6 +257,16 @@ __device__ inline double recip_scale(double s)
     return 1.0 / s;
 }
 
+// Stores of lanes without an output go to a sink, loads of lanes without an input read zeros:
+// SINK_WAVES regions of [WAVE doubles written | WAVE zeros], one per wave (modulo), so that
+// hundreds of waves do not hammer the same four cache lines of one L2 channel at every step.
+constexpr int SINK_WAVES = 4096;
+__device__ inline double *wave_sink(double *sink)
+{
+    const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    return sink + (size_t)(wid % SINK_WAVES) * 2 * WAVE + (threadIdx.x & (WAVE - 1));
+}
+
 constexpr int PF = 8;   // frames of b / alpha prefetched ahead of the serial recursion
 constexpr int PFF = 16; // the same for the forward pass (one operand stream, more room)
 
@@ -395,17 +405,14 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     return st.a;
 }
 
+// calc_alpha + calc_probability for utterance u on the 16/64 lanes of one group
 template <int L>
-__global__ void __launch_bounds__(WAVE)
-k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__ b,
-          const long long *__restrict__ off, double *__restrict__ alpha,
-          double *__restrict__ scale, double *__restrict__ sinv,
-          const double *__restrict__ lognorm, double *__restrict__ loglik,
-          double *__restrict__ sink)
+__device__ inline void forward_utt(int N, int u, int i, const double *__restrict__ A,
+                                   const double *__restrict__ b, const long long *__restrict__ off,
+                                   double *__restrict__ alpha, double *__restrict__ scale,
+                                   double *__restrict__ sinv, const double *__restrict__ lognorm,
+                                   double *__restrict__ loglik, double *__restrict__ sink)
 {
-    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
-    const int i = threadIdx.x % L;
-    if (u >= U) return;
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     if (T <= 0) {
@@ -418,7 +425,7 @@ k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__
         offband |= act && (A[j * N + i] != 0.0 && j != i && j != i - 1);
     const bool banded = !__any(offband);
     double *su = scale + f0, *si = sinv + f0;
-    double *snk = sink + (threadIdx.x & (WAVE - 1));
+    double *snk = wave_sink(sink);
     double a;
     if (banded)
         a = forward_run<L, true>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
@@ -434,6 +441,20 @@ k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__
     lp = group_sum<L>(lp);
     double last = __shfl(a, N - 1, L);
     if (i == 0) loglik[u] = lp + log(last);
+}
+
+template <int L>
+__global__ void __launch_bounds__(WAVE)
+k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__ b,
+          const long long *__restrict__ off, double *__restrict__ alpha,
+          double *__restrict__ scale, double *__restrict__ sinv,
+          const double *__restrict__ lognorm, double *__restrict__ loglik,
+          double *__restrict__ sink)
+{
+    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    const int i = threadIdx.x % L;
+    if (u >= U) return;
+    forward_utt<L>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink);
 }
 
 // The recogniser's vocabulary loop (RF:326-374) in one launch: blockIdx.y = word model.
@@ -471,7 +492,7 @@ k_forward_multi(int U, int NS, long long F, const fwd_model *__restrict__ tab,
         offband |= act && (A[j * N + i] != 0.0 && j != i && j != i - 1);
     const bool banded = !__any(offband);
     double *su = scale + (size_t)k * F + f0, *si = sinv + (size_t)k * F + f0;
-    double *snk = sink + (threadIdx.x & (WAVE - 1));
+    double *snk = wave_sink(sink);
     const double *bu = b + f0 * NS + mk.bo;
     double a;
     if (banded)
@@ -645,7 +666,7 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
     for (int j = 0; j < N; j++)
         offband |= act && (A[i * N + j] != 0.0 && j != i && j != i + 1);
     const bool banded = !__any(offband);
-    double *snk = sink + (threadIdx.x & (WAVE - 1));
+    double *snk = wave_sink(sink);
     if (banded)
         backward_run<L, true>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
                               sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
@@ -768,6 +789,7 @@ __device__ inline double block_sum_fixed(double v, double *sh)
 
 struct reduce_args {
     int N, M, D, U, delta;
+    int S; // slots of the utterance partials: one per utterance, or one per (utterance, chunk)
     // vector-ALU partials
     int P1;
     const double *part_mu, *part_var;
@@ -855,18 +877,18 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
     if (q < N * N) {
         int i = q / N, j = q % N, o = j - i;
         if (o >= 0 && o <= a.delta)
-            for (int u = tid; u < U; u += RD_THREADS)
+            for (int u = tid; u < a.S; u += RD_THREADS)
                 v += a.part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o];
         v = block_sum_fixed(v, sh);
         if (tid == 0) num_a[q] = v;
     } else if (q < N * N + N) {
         int i = q - N * N;
-        for (int u = tid; u < U; u += RD_THREADS) v += a.part_dena[(size_t)u * N + i];
+        for (int u = tid; u < a.S; u += RD_THREADS) v += a.part_dena[(size_t)u * N + i];
         v = block_sum_fixed(v, sh);
         if (tid == 0) den_a[i] = v;
     } else if (q < N * N + 2 * N) {
         int i = q - N * N - N;
-        for (int u = tid; u < U; u += RD_THREADS) v += a.part_denc[(size_t)u * N + i];
+        for (int u = tid; u < a.S; u += RD_THREADS) v += a.part_denc[(size_t)u * N + i];
         v = block_sum_fixed(v, sh);
         if (tid == 0) den_c[i] = v;
     } else {

@@ -478,8 +478,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
         const int gm = gmap[c0 * 16 + k], jj = k & 15;
         const int stt = (c0 * 16 + k) >> LOGMP;
         const bool hold = (MPL >= 4 ? (jj & (MPL - 1)) < 4 : true) && stt < N;
-        offl[2 * k] = OUT != 1 ? 0 : (gm >= 0 ? (long long)gm : (sink + jj) - post);
-        offl[2 * k + 1] = hold ? (long long)stt : (sink + 16 + jj) - b;
+        // (sink slots of this block: its first wave's region)
+        double *bsink = sink + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * EMS_WAVES % SINK_WAVES) * 2 * WAVE;
+        offl[2 * k] = OUT != 1 ? 0 : (gm >= 0 ? (long long)gm : (bsink + jj) - post);
+        offl[2 * k + 1] = hold ? (long long)stt : (bsink + 16 + jj) - b;
         strl[2 * k] = gm >= 0 ? (unsigned)G : 0u;
         strl[2 * k + 1] = hold ? (unsigned)N : 0u;
     }
@@ -494,7 +496,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
         xw[r * XS + D + e] = e == 0 ? 1.0 : 0.0;
     }
     const int q64 = 64 / D, r64 = 64 - q64 * D; // element index step 64 in (row, column) form
-    double *snk = sink + l;
+    double *snk = wave_sink(sink);
     const double *xr = xw + j * XS + kq; // A operand: frame l&15, k = 4s + (l>>4)
     // Work units = (frame tile, group of TPS Gaussian tiles), dealt to the grid's waves in
     // equal contiguous shares: with whole frame tiles per wave, 18 750 tiles on 4 096 waves
