@@ -260,6 +260,11 @@ __device__ inline double recip_scale(double s)
 // Stores of lanes without an output go to a sink, loads of lanes without an input read zeros:
 // SINK_WAVES regions of [WAVE doubles written | WAVE zeros], one per wave (modulo), so that
 // hundreds of waves do not hammer the same four cache lines of one L2 channel at every step.
+// Partial sums of the utterance statistics, one slot per utterance or per (utterance, chunk),
+// slot-minor so that k_reduce_all reads them coalesced: xi[(i, o)][slot], den[i][slot]
+__device__ inline size_t pxi_at(int slot, int i, int o, int S) { return ((size_t)i * (MAX_DELTA + 1) + o) * S + slot; }
+__device__ inline size_t pden_at(int slot, int i, int S) { return (size_t)i * S + slot; }
+
 constexpr int SINK_WAVES = 4096;
 __device__ inline double *wave_sink(double *sink)
 {
@@ -561,7 +566,7 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
                                     const double *__restrict__ si, double *__restrict__ beu,
                                     double *__restrict__ gu, double *__restrict__ part_xi,
                                     double *__restrict__ part_dena, double *__restrict__ part_denc,
-                                    double *__restrict__ sink)
+                                    double *__restrict__ sink, int S)
 {
     bwd_state<L, BANDED> st;
     st.N = N;
@@ -633,9 +638,9 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
         }
     if (act) {
         for (int o = 0; o <= delta; o++)
-            part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o] = st.aband[o] * st.xi[o];
-        part_dena[(size_t)u * N + i] = st.dena;
-        part_denc[(size_t)u * N + i] = st.dena + st.denc;
+            part_xi[pxi_at(u, i, o, S)] = st.aband[o] * st.xi[o];
+        part_dena[pden_at(u, i, S)] = st.dena;
+        part_denc[pden_at(u, i, S)] = st.dena + st.denc;
     }
 }
 
@@ -656,9 +661,9 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
     const bool act = i < N;
     if (T <= 0) {
         if (act) {
-            for (int o = 0; o <= delta; o++) part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o] = 0.0;
-            part_dena[(size_t)u * N + i] = 0.0;
-            part_denc[(size_t)u * N + i] = 0.0;
+            for (int o = 0; o <= delta; o++) part_xi[pxi_at(u, i, o, U)] = 0.0;
+            part_dena[pden_at(u, i, U)] = 0.0;
+            part_denc[pden_at(u, i, U)] = 0.0;
         }
         return;
     }
@@ -670,11 +675,11 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
     if (banded)
         backward_run<L, true>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
                               sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
-                              part_denc, snk);
+                              part_denc, snk, U);
     else
         backward_run<L, false>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
                                sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
-                               part_denc, snk);
+                               part_denc, snk, U);
 }
 
 // ---------------------------------------------------------------- mixstats
@@ -878,17 +883,17 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         int i = q / N, j = q % N, o = j - i;
         if (o >= 0 && o <= a.delta)
             for (int u = tid; u < a.S; u += RD_THREADS)
-                v += a.part_xi[((size_t)u * N + i) * (MAX_DELTA + 1) + o];
+                v += a.part_xi[pxi_at(u, i, o, a.S)];
         v = block_sum_fixed(v, sh);
         if (tid == 0) num_a[q] = v;
     } else if (q < N * N + N) {
         int i = q - N * N;
-        for (int u = tid; u < a.S; u += RD_THREADS) v += a.part_dena[(size_t)u * N + i];
+        for (int u = tid; u < a.S; u += RD_THREADS) v += a.part_dena[pden_at(u, i, a.S)];
         v = block_sum_fixed(v, sh);
         if (tid == 0) den_a[i] = v;
     } else if (q < N * N + 2 * N) {
         int i = q - N * N - N;
-        for (int u = tid; u < a.S; u += RD_THREADS) v += a.part_denc[(size_t)u * N + i];
+        for (int u = tid; u < a.S; u += RD_THREADS) v += a.part_denc[pden_at(u, i, a.S)];
         v = block_sum_fixed(v, sh);
         if (tid == 0) den_c[i] = v;
     } else {

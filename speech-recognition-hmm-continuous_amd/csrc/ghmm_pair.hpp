@@ -133,7 +133,7 @@ __device__ inline void combine_run(int N, int T, int delta, int i, bool act, int
                                    const double *__restrict__ sbu, double *__restrict__ beu,
                                    double *__restrict__ gu, double *__restrict__ part_xi,
                                    double *__restrict__ part_dena, double *__restrict__ part_denc,
-                                   double *__restrict__ sink)
+                                   double *__restrict__ sink, int S)
 {
     const double a_self = act ? A[i * N + i] : 0.0;
     const double a_next = (act && i + 1 < N) ? A[i * N + i + 1] : 0.0;
@@ -260,9 +260,9 @@ __device__ inline void combine_run(int N, int T, int delta, int i, bool act, int
         if (t - k >= tlo) frame(t - k, qw[k], qa[k], qc[k], qs[k]);
     if (act) {
         for (int o = 0; o <= delta; o++)
-            part_xi[((size_t)slot * N + i) * (MAX_DELTA + 1) + o] = aband[o] * xi[o];
-        part_dena[(size_t)slot * N + i] = dena;
-        part_denc[(size_t)slot * N + i] = denc;
+            part_xi[pxi_at(slot, i, o, S)] = aband[o] * xi[o];
+        part_dena[pden_at(slot, i, S)] = dena;
+        part_denc[pden_at(slot, i, S)] = denc;
     }
 }
 
@@ -284,9 +284,9 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
     const int tlo = (int)((long long)T * k / CB_CH), thi = (int)((long long)T * (k + 1) / CB_CH);
     if (T <= 0 || thi <= tlo) {
         if (act) {
-            for (int o = 0; o <= MAX_DELTA; o++) part_xi[((size_t)q * N + i) * (MAX_DELTA + 1) + o] = 0.0;
-            part_dena[(size_t)q * N + i] = 0.0;
-            part_denc[(size_t)q * N + i] = 0.0;
+            for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(q, i, o, U * CB_CH)] = 0.0;
+            part_dena[pden_at(q, i, U * CB_CH)] = 0.0;
+            part_denc[pden_at(q, i, U * CB_CH)] = 0.0;
         }
         return;
     }
@@ -298,11 +298,11 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
     if (banded)
         combine_run<L, true, WANT_BETA>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                         wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
-                                        part_dena, part_denc, snk);
+                                        part_dena, part_denc, snk, U * CB_CH);
     else
         combine_run<L, false, WANT_BETA>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                          wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
-                                         part_dena, part_denc, snk);
+                                         part_dena, part_denc, snk, U * CB_CH);
 }
 
 } // namespace ghmm
