@@ -92,6 +92,7 @@ struct ghmm_model {
     double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *logwkp = nullptr, *condp = nullptr;
     double *oglob = nullptr, *condg = nullptr;
     int *gmap = nullptr, *anyflag = nullptr;
+    bool banded = false; // A as last set from the host has a_ij = 0 unless j = i or i + 1
     int epoch = 0; // preparation count; anyflag[0] == epoch: this model holds an ill-conditioned Gaussian
     int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
 };
@@ -446,6 +447,10 @@ extern "C" int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, con
     if (rc) return rc;
     ARG_CHECK(m && A && c && mean && inv_var && det, "null argument");
     size_t G = (size_t)m->N * m->M, NN = (size_t)m->N * m->N;
+    m->banded = true;
+    for (int i = 0; i < m->N; i++)
+        for (int j = 0; j < m->N; j++)
+            if (A[(size_t)i * m->N + j] != 0.0 && j != i && j != i + 1) m->banded = false;
     HIP_TRY(hipMemcpyAsync(m->A, A, NN * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(m->c, c, G * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(m->mean, mean, G * m->D * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -912,16 +917,22 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
                 ctx->own_bwd_done = true;
             }
             const unsigned cb = (unsigned)(((long long)c->U * CB_CH + gpw - 1) / gpw);
-#define GHMM_COMBINE(LL, WB)                                                                       \
-    hipLaunchKernelGGL((k_combine<LL, WB>), dim3(cb), dim3(WAVE), 0, ctx->stream, m->N, c->U,      \
+#define GHMM_COMBINE(LL, WB, DN)                                                                   \
+    hipLaunchKernelGGL((k_combine<LL, WB, DN>), dim3(cb), dim3(WAVE), 0, ctx->stream, m->N, c->U,  \
                        (int)ctx->delta, m->A, c->off, ctx->alpha, ctx->scale, ctx->wrow, ctx->sb, \
                        ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink)
-            if (L == 16) {
-                if (want_beta) GHMM_COMBINE(16, true);
-                else GHMM_COMBINE(16, false);
+            // the M-step keeps a band-diagonal A band-diagonal as long as it re-estimates
+            // no transition beyond i -> i + 1
+            const bool band2 = m->banded && ctx->delta <= 1;
+            if (L == 16 && band2) {
+                if (want_beta) GHMM_COMBINE(16, true, false);
+                else GHMM_COMBINE(16, false, false);
+            } else if (L == 16) {
+                if (want_beta) GHMM_COMBINE(16, true, true);
+                else GHMM_COMBINE(16, false, true);
             } else {
-                if (want_beta) GHMM_COMBINE(64, true);
-                else GHMM_COMBINE(64, false);
+                if (want_beta) GHMM_COMBINE(64, true, true);
+                else GHMM_COMBINE(64, false, true);
             }
             ctx->beta_valid = want_beta;
             ctx->last_m = m;

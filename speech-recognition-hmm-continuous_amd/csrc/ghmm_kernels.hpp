@@ -637,8 +637,9 @@ __device__ inline void backward_run(int N, int T, int delta, int i, bool act, in
             pbe -= dn; pg -= dn;
         }
     if (act) {
-        for (int o = 0; o <= delta; o++)
-            part_xi[pxi_at(u, i, o, S)] = st.aband[o] * st.xi[o];
+#pragma unroll
+        for (int o = 0; o <= MAX_DELTA; o++) // compile-time indices: the arrays stay in registers
+            if (o <= delta) part_xi[pxi_at(u, i, o, S)] = st.aband[o] * st.xi[o];
         part_dena[pden_at(u, i, S)] = st.dena;
         part_denc[pden_at(u, i, S)] = st.dena + st.denc;
     }

@@ -25,7 +25,7 @@
 namespace ghmm {
 
 constexpr int CB_CH = 8; // chunks of an utterance handled by different groups of k_combine
-constexpr int CB_PF = 4; // frames of operands read ahead in k_combine
+constexpr int CB_PF = 4; // frames of operands read ahead in k_combine (x 2 register sets x 4 operands)
 
 template <int L, bool BANDED>
 __device__ inline void backward_own_run(int N, int T, int i, bool act, const double *__restrict__ A,
@@ -126,8 +126,9 @@ k_scan_pair(int N, int U, int only, const double *__restrict__ A, const double *
 
 // gamma, the xi / den sums (one partial slot per (utterance, chunk)) and optionally beta^ from
 // alpha^, c, W and 1/s.  Group = (utterance, chunk of its frames), frames descending.
-template <int L, bool BANDED, bool WANT_BETA>
-__device__ inline void combine_run(int N, int T, int delta, int i, bool act, int slot, int tlo, int thi,
+// MD = widest band offset that can carry statistics (delta <= MD)
+template <int L, bool BANDED, bool WANT_BETA, int MD = MAX_DELTA>
+__device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool act, int slot, int tlo, int thi,
                                    const double *__restrict__ A, const double *__restrict__ au,
                                    const double *__restrict__ su, const double *__restrict__ wu,
                                    const double *__restrict__ sbu, double *__restrict__ beu,
@@ -142,9 +143,9 @@ __device__ inline void combine_run(int N, int T, int delta, int i, bool act, int
 #pragma unroll
         for (int j = 0; j < L; j++) arow[BANDED ? 0 : j] = (act && j < N) ? A[i * N + j] : 0.0;
     }
-    double aband[MAX_DELTA + 1], xi[MAX_DELTA + 1];
+    double aband[MD + 1], xi[MD + 1];
 #pragma unroll
-    for (int o = 0; o <= MAX_DELTA; o++) {
+    for (int o = 0; o <= MD; o++) {
         aband[o] = (act && i + o < N && o <= delta) ? A[i * N + i + o] : 0.0;
         xi[o] = 0.0;
     }
@@ -213,7 +214,7 @@ __device__ inline void combine_run(int N, int T, int delta, int i, bool act, int
         xi[0] = fma(al * w, rho1, xi[0]);
         xi[1] = fma(al * wd, rho1, xi[1]);
 #pragma unroll
-        for (int o = 2; o <= MAX_DELTA; o++)
+        for (int o = 2; o <= MD; o++)
             if (o <= delta) {
                 const double wj = __shfl_down(w, o, L);
                 xi[o] += (i + o < N) ? al * wj * rho1 : 0.0;
@@ -259,15 +260,19 @@ __device__ inline void combine_run(int N, int T, int delta, int i, bool act, int
     for (int k = 0; k < CB_PF - 1; k++)
         if (t - k >= tlo) frame(t - k, qw[k], qa[k], qc[k], qs[k]);
     if (act) {
-        for (int o = 0; o <= delta; o++)
-            part_xi[pxi_at(slot, i, o, S)] = aband[o] * xi[o];
+#pragma unroll
+        for (int o = 0; o <= MD; o++) // compile-time indices: the arrays stay in registers
+            if (o <= delta) part_xi[pxi_at(slot, i, o, S)] = aband[o] * xi[o];
         part_dena[pden_at(slot, i, S)] = dena;
         part_denc[pden_at(slot, i, S)] = denc;
     }
 }
 
-template <int L, bool WANT_BETA>
-__global__ void __launch_bounds__(WAVE, 2)
+// DENSE = false: A is known (on the host, ghmm_model_set) to be band-diagonal with a_ij = 0
+// unless j = i or i + 1, only that form is compiled (half the registers, twice the waves in
+// flight); DENSE = true decides per wave on the device like the one-pass kernels.
+template <int L, bool WANT_BETA, bool DENSE>
+__global__ void __launch_bounds__(WAVE, DENSE ? 2 : 4)
 k_combine(int N, int U, int delta, const double *__restrict__ A, const long long *__restrict__ off,
           const double *__restrict__ alpha, const double *__restrict__ scale,
           const double *__restrict__ wrow, const double *__restrict__ sb, double *__restrict__ beta,
@@ -290,16 +295,19 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
         }
         return;
     }
-    bool offband = false;
-    for (int j = 0; j < N; j++)
-        offband |= act && (A[i * N + j] != 0.0 && j != i && j != i + 1);
-    const bool banded = !__any(offband);
     double *snk = wave_sink(sink);
+    bool banded = true;
+    if (DENSE) {
+        bool offband = false;
+        for (int j = 0; j < N; j++)
+            offband |= act && (A[i * N + j] != 0.0 && j != i && j != i + 1);
+        banded = !__any(offband);
+    }
     if (banded)
-        combine_run<L, true, WANT_BETA>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
+        combine_run<L, true, WANT_BETA, DENSE ? MAX_DELTA : 1>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                         wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
                                         part_dena, part_denc, snk, U * CB_CH);
-    else
+    else if (DENSE)
         combine_run<L, false, WANT_BETA>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                          wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
                                          part_dena, part_denc, snk, U * CB_CH);
