@@ -62,8 +62,9 @@ struct ghmm_ctx {
     double *sink = nullptr; // [0,64): idle lanes' stores land here; [64,128): zeros they read
     double *part_xi = nullptr, *part_dena = nullptr, *part_denc = nullptr;
     // paired scans (ghmm_pair.hpp): W rows and 1/s_t of the backward pass with its own normaliser
-    double *wrow = nullptr, *sb = nullptr;
-    size_t cap_wrow = 0, cap_sb = 0;
+    double *wrow = nullptr, *sb = nullptr, *lpart = nullptr, *logk = nullptr;
+    size_t cap_wrow = 0, cap_sb = 0, cap_lpart = 0, cap_logk = 0;
+    bool loglik_pieces = false; // log P of the last E-step is in lpart / logk, loglik[] not assembled
     bool own_bwd_done = false; // k_scan_pair ran the backward direction for the current alpha
     bool beta_valid = false;   // ctx->beta holds the reference's beta^
     // what the last gamma / xi pass ran on, so that ghmm_fetch(GHMM_BUF_BETA) can form beta^ when
@@ -236,7 +237,8 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     void *bufs[] = {ctx->b,       ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
-                    ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb};
+                    ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb,
+                    ctx->lpart,   ctx->logk};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (auto &t : ctx->kt) {
@@ -693,6 +695,8 @@ static int ws_fb(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
     size_t FN = (size_t)c->F * m->N, UN = (size_t)c->U * m->N * CB_CH; // one slot per (utterance, chunk)
     if ((rc = dev_grow(&ctx->wrow, &ctx->cap_wrow, FN))) return rc;
     if ((rc = dev_grow(&ctx->sb, &ctx->cap_sb, (size_t)c->F))) return rc;
+    if ((rc = dev_grow(&ctx->lpart, &ctx->cap_lpart, (size_t)c->U * CB_CH))) return rc;
+    if ((rc = dev_grow(&ctx->logk, &ctx->cap_logk, (size_t)c->U))) return rc;
     if ((rc = dev_grow(&ctx->alpha, &ctx->cap_alpha, FN))) return rc;
     if ((rc = dev_grow(&ctx->beta, &ctx->cap_beta, FN))) return rc;
     if ((rc = dev_grow(&ctx->gamma, &ctx->cap_gamma, FN))) return rc;
@@ -867,6 +871,7 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_b
     const double *ln = ctx->robust ? ctx->lognorm : nullptr;
     ctx->own_bwd_done = false;
     ctx->beta_valid = false;
+    ctx->loglik_pieces = use_pair(ctx) && with_backward; // k_combine will take the logs
     {
         kscope ks(ctx, GHMM_K_FORWARD);
         if (use_pair(ctx)) {
@@ -920,7 +925,9 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
 #define GHMM_COMBINE(LL, WB, DN)                                                                   \
     hipLaunchKernelGGL((k_combine<LL, WB, DN>), dim3(cb), dim3(WAVE), 0, ctx->stream, m->N, c->U,  \
                        (int)ctx->delta, m->A, c->off, ctx->alpha, ctx->scale, ctx->wrow, ctx->sb, \
-                       ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink)
+                       ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, \
+                       ctx->robust ? ctx->lognorm : (const double *)nullptr,                     \
+                       ctx->loglik_pieces ? ctx->lpart : (double *)nullptr, ctx->logk)
             // the M-step keeps a band-diagonal A band-diagonal as long as it re-estimates
             // no transition beyond i -> i + 1
             const bool band2 = m->banded && ctx->delta <= 1;
@@ -1097,6 +1104,8 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         reduce_args ra;
         ra.N = N; ra.M = M; ra.D = D; ra.U = c->U; ra.delta = (int)ctx->delta;
         ra.S = ctx->slots;
+        ra.lpart = ctx->loglik_pieces ? ctx->lpart : nullptr;
+        ra.logk = ctx->logk;
         ra.P1 = (int)P; ra.part_mu = ctx->part_mu; ra.part_var = ctx->part_var;
         ra.Pm = (mfma && c->F > 0) ? Pm : 0;
         ra.NT = m->NT; ra.DP = m->DP; ra.ES = m->NE * 16;
@@ -1160,7 +1169,15 @@ extern "C" int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n)
         break;
     case GHMM_BUF_SCALE: src = ctx->scale; have = F; break;
     case GHMM_BUF_GAMMA: src = ctx->gamma; have = F * N; break;
-    case GHMM_BUF_LOGLIK: src = ctx->loglik; have = U; break;
+    case GHMM_BUF_LOGLIK:
+        if (ctx->loglik_pieces && ctx->loglik && U) {
+            hipLaunchKernelGGL(k_loglik_assemble, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (int)U, ctx->lpart, ctx->logk, ctx->loglik);
+            ctx->loglik_pieces = false; // loglik[] is complete now (the pieces stay valid too)
+        }
+        src = ctx->loglik;
+        have = U;
+        break;
     case GHMM_BUF_LOGNORM: src = ctx->lognorm; have = F; break;
     default:
         ghmm_set_error("unknown buffer %d", which);

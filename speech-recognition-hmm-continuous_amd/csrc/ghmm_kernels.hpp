@@ -416,12 +416,13 @@ __device__ inline void forward_utt(int N, int u, int i, const double *__restrict
                                    const double *__restrict__ b, const long long *__restrict__ off,
                                    double *__restrict__ alpha, double *__restrict__ scale,
                                    double *__restrict__ sinv, const double *__restrict__ lognorm,
-                                   double *__restrict__ loglik, double *__restrict__ sink)
+                                   double *__restrict__ loglik, double *__restrict__ sink,
+                                   bool want_logp = true)
 {
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     if (T <= 0) {
-        if (i == 0) loglik[u] = 0.0;
+        if (i == 0 && want_logp) loglik[u] = 0.0;
         return;
     }
     const bool act = i < N;
@@ -436,6 +437,7 @@ __device__ inline void forward_utt(int N, int u, int i, const double *__restrict
         a = forward_run<L, true>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
     else
         a = forward_run<L, false>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
+    if (!want_logp) return; // k_combine takes the logs, spread over all of its waves
     // log P: the T logs are spread over the group's lanes instead of a serial loop
     __threadfence_block();
     double lp = 0.0;
@@ -806,6 +808,9 @@ struct reduce_args {
     double cond_max;
     // utterance partials
     const double *part_xi, *part_dena, *part_denc, *loglik;
+    // log P in pieces (ghmm_pair.hpp): -sum log c_t per slot and log alpha^_{T-1}(N-1) per utterance;
+    // nullptr: loglik[u] is complete
+    const double *lpart, *logk;
     double *stats;
 };
 
@@ -898,7 +903,12 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         v = block_sum_fixed(v, sh);
         if (tid == 0) den_c[i] = v;
     } else {
-        for (int u = tid; u < U; u += RD_THREADS) v += a.loglik[u];
+        if (a.lpart) {
+            for (int u = tid; u < a.S; u += RD_THREADS) v += a.lpart[u];
+            for (int u = tid; u < U; u += RD_THREADS) v += a.logk[u];
+        } else {
+            for (int u = tid; u < U; u += RD_THREADS) v += a.loglik[u];
+        }
         v = block_sum_fixed(v, sh);
         if (tid == 0) {
             num_var[(size_t)G * D] = v;            // loglik

@@ -106,7 +106,8 @@ k_scan_pair(int N, int U, int only, const double *__restrict__ A, const double *
     if (u >= U) return;
     const int dir = only >= 0 ? only : (int)blockIdx.y;
     if (dir == 0) {
-        forward_utt<L>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink);
+        // with the backward direction alongside, k_combine follows and takes the logs of log P
+        forward_utt<L>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink, only == 0);
         return;
     }
     const long long f0 = off[u];
@@ -277,7 +278,8 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
           const double *__restrict__ alpha, const double *__restrict__ scale,
           const double *__restrict__ wrow, const double *__restrict__ sb, double *__restrict__ beta,
           double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
-          double *__restrict__ part_denc, double *__restrict__ sink)
+          double *__restrict__ part_denc, double *__restrict__ sink,
+          const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk)
 {
     const int q = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
@@ -287,6 +289,20 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
     const int T = (int)(off[u + 1] - f0);
     const bool act = i < N;
     const int tlo = (int)((long long)T * k / CB_CH), thi = (int)((long long)T * (k + 1) / CB_CH);
+    if (lpart) {
+        // calc_probability (TF:1536-1553) in pieces: this chunk's -sum log c_t (+ the robust
+        // mode's normalisers), and log alpha^_{T-1}(N-1) from the chunk that ends the utterance
+        double lp = 0.0;
+        for (int t = tlo + i; t < thi; t += L) {
+            lp -= log(scale[f0 + t]);
+            if (lognorm) lp += lognorm[f0 + t];
+        }
+        lp = group_sum<L>(lp);
+        if (i == 0) {
+            lpart[q] = lp;
+            if (k == CB_CH - 1) logk[u] = T > 0 ? log(alpha[(f0 + T - 1) * N + (N - 1)]) : 0.0;
+        }
+    }
     if (T <= 0 || thi <= tlo) {
         if (act) {
             for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(q, i, o, U * CB_CH)] = 0.0;
@@ -313,4 +329,18 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
                                          part_dena, part_denc, snk, U * CB_CH);
 }
 
+} // namespace ghmm
+
+namespace ghmm {
+// log P per utterance from the pieces k_combine left (only when somebody asks for the vector)
+__global__ void __launch_bounds__(256)
+k_loglik_assemble(int U, const double *__restrict__ lpart, const double *__restrict__ logk,
+                  double *__restrict__ loglik)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= U) return;
+    double lp = 0.0;
+    for (int k = 0; k < CB_CH; k++) lp += lpart[(size_t)u * CB_CH + k];
+    loglik[u] = lp + logk[u];
+}
 } // namespace ghmm
