@@ -74,7 +74,9 @@ enum {
      * 1: per-frame max-normalised densities (finite where the reference is not;
      *    the log of the normaliser is added back into the log-likelihood). */
     GHMM_OPT_ROBUST = 2,
-    /* 0 auto, 1 vector-ALU kernels, 2 MFMA (f64 16x16x4) kernels */
+    /* 0 auto, 1 vector-ALU kernels and the reference's order of the recursions (calc_alpha,
+     * then calc_beta scaled by its c_t, one pass each), 2 MFMA (f64 16x16x4) kernels and the
+     * forward / backward recursions side by side (what auto picks) */
     GHMM_OPT_KERNELS = 3,
     /* 1: bracket every kernel with HIP events on the context's stream */
     GHMM_OPT_TIMING = 4,
@@ -188,7 +190,8 @@ enum {
     GHMM_BUF_B = 0,      /* b[F][N]        symbol_probab        TF:107 */
     GHMM_BUF_POST = 1,   /* post[F][N*M]   gaus_probab_dens     TF:110 */
     GHMM_BUF_ALPHA = 2,  /* alpha^[F][N]                        TF:112 */
-    GHMM_BUF_BETA = 3,   /* beta^[F][N]                         TF:114 */
+    GHMM_BUF_BETA = 3,   /* beta^[F][N]                         TF:114; after ghmm_estep it is formed on
+                          * this call (the E-step itself only needs gamma and xi) */
     GHMM_BUF_SCALE = 4,  /* c_t[F]         scaling_factor       TF:116 */
     GHMM_BUF_GAMMA = 5,  /* gamma[F][N] = alpha^*beta^/c_t      TF:1657 */
     GHMM_BUF_LOGLIK = 6, /* log P per utterance [U]             TF:1536 */
@@ -198,8 +201,8 @@ int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n_doubles);
 
 /* -------------------------------------------------- the path, batched/fused */
 
-/* One E-step over the whole corpus: emission -> forward -> backward ->
- * statistics -> ordered reduction (TF:244-321).  `stats` is overwritten (the
+/* One E-step over the whole corpus: emission -> forward and backward recursions ->
+ * gamma / xi -> statistics -> ordered reduction (TF:244-321).  `stats` is overwritten (the
  * zeroing of TF:244-270 is implied).  Asynchronous on the context's stream. */
 int ghmm_estep(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *stats);
 /* M-step from (possibly all-reduced) statistics, on the device, in place:
