@@ -334,6 +334,60 @@ def test_both_kernel_tiers(G, ctx, tier, load_case):
         ctx.set_option(G.OPT_KERNELS, 0)
 
 
+@pytest.mark.parametrize("N,M,D,lens,dense,delta", [
+    (10, 8, 39, [300, 211, 77, 5, 1, 2, 33], False, 1),   # ragged, T < N (kappa = 0), T = 1
+    (6, 2, 7, [50, 60, 3], True, 1),                      # dense A: general recursion
+    (6, 2, 7, [50, 60, 9], True, 3),                      # wider transition band
+    (20, 2, 9, [60, 45], True, 1),                        # N > 16: one wave per utterance
+])
+def test_paired_scans_equal_the_reference_order(G, ctx, N, M, D, lens, dense, delta):
+    """The default tier runs the backward recursion with its own normaliser beside the forward
+    pass and forms gamma / xi / beta^ from the scaling identity sum_i alpha^ beta^ = c_t kappa
+    (ghmm_pair.hpp); GHMM_OPT_KERNELS = 1 keeps the reference's order (calc_beta scaled by
+    calc_alpha's c_t, TF:1463-1516).  Same gamma, beta^, log P and statistics."""
+    hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    F = corpus.frames
+    out = {}
+    try:
+        ctx.set_option(G.OPT_DELTA, delta)
+        for tier in (1, 0):
+            ctx.set_option(G.OPT_KERNELS, tier)
+            stats = ctx.stats(N, M, D)
+            ctx.estep(model, corpus, stats)
+            out[tier] = dict(stats=stats.download(), beta=ctx.fetch(G.BUF_BETA, (F, N)),
+                             gamma=ctx.fetch(G.BUF_GAMMA, (F, N)), ll=ctx.fetch(G.BUF_LOGLIK, (len(lens),)))
+            stats.close()
+    finally:
+        ctx.set_option(G.OPT_KERNELS, 0)
+        ctx.set_option(G.OPT_DELTA, 1)
+    for k in ("gamma", "beta", "ll", "stats"):
+        assert_close(out[0][k], out[1][k], rtol=1e-9, what=k)
+    for o in (model, corpus):
+        o.close()
+
+
+def test_beta_on_demand_follows_the_model(G, ctx):
+    """ghmm_estep leaves beta^ out; ghmm_fetch forms it from the E-step's alpha^ / W while the model
+    is unchanged, and refuses once ghmm_mstep has replaced the parameters they belong to."""
+    hm, X, lens = synth_case(G, 5, 2, 6, [40, 25])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(5, 2, 6)
+    _, ref = O.estep(hm, X, lens)
+    ctx.estep(model, corpus, stats)
+    assert_close(ctx.fetch(G.BUF_BETA, (corpus.frames, 5)), ref["beta"], what="beta after estep")
+    ctx.estep(model, corpus, stats)
+    ctx.mstep(model, stats)
+    with pytest.raises(G.GhmmError):
+        ctx.fetch(G.BUF_BETA, (corpus.frames, 5))
+    ctx.emission(model, corpus, True)      # the row API on the new model brings it back
+    ctx.forward(model, corpus)
+    ctx.backward(model, corpus)
+    assert np.isfinite(ctx.fetch(G.BUF_BETA, (corpus.frames, 5))).all()
+    for o in (model, corpus, stats):
+        o.close()
+
+
 def test_ten_em_iterations_track_the_oracle(G, ctx):
     """Fixed iteration count (the benchmark mode): the per-iteration log-likelihood and
     the final model stay within 1e-7 of the oracle over 10 E+M steps."""
