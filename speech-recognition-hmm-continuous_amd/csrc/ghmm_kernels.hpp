@@ -410,6 +410,29 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     return st.a;
 }
 
+// -sum_t log c_t without a log per frame: the product of the mantissas and the sum of the exponents
+// (v_frexp_mant/exp + one multiply and one add per value), one log at the end.  0, inf and NaN
+// behave like log()'s sum: the mantissa of 0 / inf / NaN is itself.
+struct log_product {
+    double m = 1.0;
+    long long e = 0;
+    int n = 0;
+    __device__ inline void mul(double c)
+    {
+        m *= __builtin_amdgcn_frexp_mant(c);
+        e += __builtin_amdgcn_frexp_exp(c);
+        if (++n == 512) { // keep the product of mantissas (each in [0.5, 1)) away from underflow
+            e += __builtin_amdgcn_frexp_exp(m);
+            m = __builtin_amdgcn_frexp_mant(m);
+            n = 0;
+        }
+    }
+    __device__ inline double log_value() const
+    {
+        return fma((double)e, 6.93147180369123816490e-01, fma((double)e, 1.90821492927058770002e-10, log(m)));
+    }
+};
+
 // calc_alpha + calc_probability for utterance u on the 16/64 lanes of one group
 template <int L>
 __device__ inline void forward_utt(int N, int u, int i, const double *__restrict__ A,
@@ -441,11 +464,12 @@ __device__ inline void forward_utt(int N, int u, int i, const double *__restrict
     // log P: the T logs are spread over the group's lanes instead of a serial loop
     __threadfence_block();
     double lp = 0.0;
+    log_product pc;
     for (int t = i; t < T; t += L) {
-        lp -= log(su[t]);
+        pc.mul(su[t]);
         if (lognorm) lp += lognorm[f0 + t];
     }
-    lp = group_sum<L>(lp);
+    lp = group_sum<L>(lp - pc.log_value());
     double last = __shfl(a, N - 1, L);
     if (i == 0) loglik[u] = lp + log(last);
 }

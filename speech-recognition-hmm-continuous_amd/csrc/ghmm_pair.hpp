@@ -293,11 +293,12 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
         // calc_probability (TF:1536-1553) in pieces: this chunk's -sum log c_t (+ the robust
         // mode's normalisers), and log alpha^_{T-1}(N-1) from the chunk that ends the utterance
         double lp = 0.0;
+        log_product pc;
         for (int t = tlo + i; t < thi; t += L) {
-            lp -= log(scale[f0 + t]);
+            pc.mul(scale[f0 + t]);
             if (lognorm) lp += lognorm[f0 + t];
         }
-        lp = group_sum<L>(lp);
+        lp = group_sum<L>(lp - pc.log_value());
         if (i == 0) {
             lpart[q] = lp;
             if (k == CB_CH - 1) logk[u] = T > 0 ? log(alpha[(f0 + T - 1) * N + (N - 1)]) : 0.0;
