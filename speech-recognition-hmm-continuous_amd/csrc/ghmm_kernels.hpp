@@ -310,6 +310,8 @@ template <int L, bool BANDED> struct fwd_state {
     // Banded A (what the reference's trainer always produces): a 2-term update.  (Taking
     // the 16-lane sum off this chain via sum_j alpha^_{t-1}(j) g_j(t) was measured slower:
     // a lone wave per SIMD is bound by instruction count, ~13 cycles each, not by the chain.)
+    // SINV: lane 1 keeps 1/c_t = sum_i alpha_t(i) for the reference-order backward pass
+    template <bool SINV>
     __device__ inline void step_banded(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
     {
         const double v = fma(a, a_self, group_up1<L>(a) * a_prev) * bt;
@@ -317,8 +319,9 @@ template <int L, bool BANDED> struct fwd_state {
         const double c = recip_fast(s);
         a = v * c;
         *pa = a;
-        *pcs = (i == 0) ? c : s;
+        *pcs = (SINV && i != 0) ? s : c;
     }
+    template <bool SINV>
     __device__ inline void step_dense(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
     {
         double aux = 0.0;
@@ -330,12 +333,12 @@ template <int L, bool BANDED> struct fwd_state {
         const double c = recip_select(s);
         a = v * c;
         *pa = a;
-        *pcs = (i == 0) ? c : s;
+        *pcs = (SINV && i != 0) ? s : c;
     }
 };
 
-template <int L, bool BANDED>
-__device__ inline double forward_run(int N, int T, int i, bool act, const double *__restrict__ A,
+template <int L, bool BANDED, bool SINV = true>
+__device__ __forceinline__ double forward_run(int N, int T, int i, bool act, const double *__restrict__ A,
                                      const double *__restrict__ bu, double *__restrict__ au,
                                      double *__restrict__ su, double *__restrict__ si,
                                      double *__restrict__ sink, int bstride)
@@ -353,8 +356,8 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     // c_t, lane 1 writes 1/c_t = sum_i alpha_t(i), the rest write the sink
     double *pa = (act && au) ? au + i : sink; // au == nullptr: scoring only, alpha^ not kept
     const int da = (act && au) ? N : 0;
-    double *pcs = (i == 0) ? su : (i == 1 ? si : sink);
-    const int dc = (i < 2) ? 1 : 0;
+    double *pcs = (i == 0) ? su : ((SINV && i == 1) ? si : sink);
+    const int dc = (i == 0 || (SINV && i == 1)) ? 1 : 0;
     const double *pb = act ? bu + i : sink + WAVE; // frame 0 of b (idle lanes: zeros, stride 0)
     const int db = act ? bstride : 0;
     // b of frame f, clamped into the utterance: loads are never predicated (a load under
@@ -370,7 +373,7 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
         const double c = recip_select(s);
         st.a = a0 * c;
         *pa = st.a;
-        *pcs = (i == 0) ? c : s;
+        *pcs = (SINV && i != 0) ? s : c;
         pa += da; pcs += dc;
     }
     double bq[PFF];
@@ -384,13 +387,13 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
         if (BANDED) {
 #pragma unroll
             for (int k = 0; k < PFF; k++) {
-                st.step_banded(bq[k], pa, pcs, i);
+                st.template step_banded<SINV>(bq[k], pa, pcs, i);
                 pa += da; pcs += dc;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < PFF; k++) {
-                st.step_dense(bq[k], pa, pcs, i);
+                st.template step_dense<SINV>(bq[k], pa, pcs, i);
                 pa += da; pcs += dc;
             }
         }
@@ -401,9 +404,9 @@ __device__ inline double forward_run(int N, int T, int i, bool act, const double
     for (int k = 0; k < PFF - 1; k++)
         if (t + k < T) {
             if (BANDED) {
-                st.step_banded(bq[k], pa, pcs, i);
+                st.template step_banded<SINV>(bq[k], pa, pcs, i);
             } else {
-                st.step_dense(bq[k], pa, pcs, i);
+                st.template step_dense<SINV>(bq[k], pa, pcs, i);
             }
             pa += da; pcs += dc;
         }
@@ -434,7 +437,7 @@ struct log_product {
 };
 
 // calc_alpha + calc_probability for utterance u on the 16/64 lanes of one group
-template <int L>
+template <int L, bool SINV = true>
 __device__ inline void forward_utt(int N, int u, int i, const double *__restrict__ A,
                                    const double *__restrict__ b, const long long *__restrict__ off,
                                    double *__restrict__ alpha, double *__restrict__ scale,
@@ -457,9 +460,9 @@ __device__ inline void forward_utt(int N, int u, int i, const double *__restrict
     double *snk = wave_sink(sink);
     double a;
     if (banded)
-        a = forward_run<L, true>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
+        a = forward_run<L, true, SINV>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
     else
-        a = forward_run<L, false>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
+        a = forward_run<L, false, SINV>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
     if (!want_logp) return; // k_combine takes the logs, spread over all of its waves
     // log P: the T logs are spread over the group's lanes instead of a serial loop
     __threadfence_block();
@@ -586,7 +589,7 @@ template <int L, bool BANDED> struct bwd_state {
 };
 
 template <int L, bool BANDED>
-__device__ inline void backward_run(int N, int T, int delta, int i, bool act, int u,
+__device__ __forceinline__ void backward_run(int N, int T, int delta, int i, bool act, int u,
                                     const double *__restrict__ A, const double *__restrict__ bu,
                                     const double *__restrict__ au, const double *__restrict__ su,
                                     const double *__restrict__ si, double *__restrict__ beu,

@@ -28,7 +28,7 @@ constexpr int CB_CH = 8; // chunks of an utterance handled by different groups o
 constexpr int CB_PF = 4; // frames of operands read ahead in k_combine (x 2 register sets x 4 operands)
 
 template <int L, bool BANDED>
-__device__ inline void backward_own_run(int N, int T, int i, bool act, const double *__restrict__ A,
+__device__ __forceinline__ void backward_own_run(int N, int T, int i, bool act, const double *__restrict__ A,
                                         const double *__restrict__ bu, double *__restrict__ wu,
                                         double *__restrict__ sbu, double *__restrict__ sink)
 {
@@ -107,7 +107,7 @@ k_scan_pair(int N, int U, int only, const double *__restrict__ A, const double *
     const int dir = only >= 0 ? only : (int)blockIdx.y;
     if (dir == 0) {
         // with the backward direction alongside, k_combine follows and takes the logs of log P
-        forward_utt<L>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink, only == 0);
+        forward_utt<L, false>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink, only == 0);
         return;
     }
     const long long f0 = off[u];
