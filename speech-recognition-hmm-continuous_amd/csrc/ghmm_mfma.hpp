@@ -444,6 +444,37 @@ template <int MP> __device__ inline double segment_max_t(double v)
     return v;
 }
 
+// State sums by a transposing butterfly: at the xor-1 and xor-2 levels each lane keeps only the
+// rows whose index matches its lane bits and sends the others, so that after the sums lane j holds
+// the sum of ONE row, r = j & 3 (MPL >= 4), or of two rows r = (j & 1) and 2 + (j & 1)
+// (MPL == 2).  The additions pair the same lanes as a plain butterfly: bit-identical sums.
+template <int MPL, int NV>
+__device__ inline void transposed_sums(const double (&tot)[4], int j, double (&sv)[NV])
+{
+    if (MPL == 1) {
+#pragma unroll
+        for (int r = 0; r < NV; r++) sv[r] = tot[r % 4];
+    } else {
+        const bool o0 = (j & 1) != 0;
+        double k0 = o0 ? tot[1] : tot[0], k1 = o0 ? tot[3] : tot[2];
+        const double s0 = o0 ? tot[0] : tot[1], s1 = o0 ? tot[2] : tot[3];
+        k0 += dpp_f64<DPP_QUAD_XOR1>(s0);
+        k1 += dpp_f64<DPP_QUAD_XOR1>(s1);
+        if (MPL == 2) {
+            sv[0] = k0;
+            sv[NV - 1] = k1;
+        } else {
+            const bool o1 = (j & 2) != 0;
+            double kk = o1 ? k1 : k0;
+            const double ss = o1 ? k0 : k1;
+            kk += dpp_f64<DPP_QUAD_XOR2>(ss);
+            if (MPL >= 8) kk += dpp_xor4_f64(kk);
+            if (MPL >= 16) kk += dpp_f64<DPP_ROW_ROR8>(kk);
+            sv[0] = kk;
+        }
+    }
+}
+
 // OUT 0: b (recogniser, RF:860-889); 1: b and posteriors (trainer, TF:1749-1783);
 // 2: log b for the Viterbi lattice, m + log(sum exp(e - m)) like the oracle's definition
 template <int KS, int MP, int OUT>
@@ -582,8 +613,6 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                     for (int r = 0; r < 4; r++) e[tt][r] *= wkj;
                 }
             }
-            const int st = ((c0 + ct) * 16 + j) >> LOGMP;
-            const bool bown = ((j & (MPL - 1)) == 0) && st < N;
             if (OUT == 2) {
                 double mx[4];
 #pragma unroll
@@ -604,23 +633,30 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
 #pragma unroll
                     for (int r = 0; r < 4; r++) sum4[r] += ex[r];
                 }
+                // sum over the state's lanes transposed: one (frame, state) and one log per lane
+                constexpr int NV2 = MPL >= 4 ? 1 : (MPL == 2 ? 2 : 4);
+                double s4[4] = {sum4[0], sum4[1], sum4[2], sum4[3]}, sv2[NV2];
+                transposed_sums<MPL, NV2>(s4, j, sv2);
+                const long long boff2 = offl[2 * (ct * 16 + j) + 1];
+                const unsigned bstr2 = strl[2 * (ct * 16 + j) + 1];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double sm = segment_sum_t<MPL>(sum4[r]);
-                    const double lb = mx[r] < -1.0e299 ? -INFINITY : mx[r] + log(sm);
-                    const long long fr = f0 + kq + 4 * r;
-                    double *pb = (bown && fr < F) ? b + fr * N + st : snk;
+                for (int v = 0; v < NV2; v++) {
+                    const int rw = MPL >= 4 ? (j & 3) : (MPL == 2 ? 2 * v + (j & 1) : v);
+                    double mxr;
+                    if (MPL >= 4) mxr = (j & 2) ? ((j & 1) ? mx[3] : mx[2]) : ((j & 1) ? mx[1] : mx[0]);
+                    else if (MPL == 2) mxr = (j & 1) ? mx[(2 * v + 1) % 4] : mx[(2 * v) % 4];
+                    else mxr = mx[v % 4];
+                    const double lb = mxr < -1.0e299 ? -INFINITY : mxr + log(sv2[v]);
+                    double *pb = b + ((unsigned long long)((unsigned)(f0 + kq) + 4 * rw) * bstr2 + boff2);
+                    pb = f0 + kq + 4 * rw < F ? pb : snk;
                     *pb = lb;
                 }
                 continue;
             }
-            // State sums by a transposing butterfly: at the xor-1 and xor-2 levels each lane
-            // keeps only the rows whose index matches its lane bits and sends the others, so
-            // that after the sums lane j holds b_i of ONE row, r = j & 3 (MPL >= 4), or of two
-            // rows r = (j & 1) and 2 + (j & 1) (MPL == 2).  The reciprocal for the posteriors
-            // (TF:1773-1778) is then formed once per (frame, state) instead of once per lane
-            // and row, and handed back to the state's lanes by quad broadcasts.  The additions
-            // pair the same lanes as a plain butterfly: bit-identical sums.
+            // state sums, transposed: one (frame, state) per lane (transposed_sums above).  The
+            // reciprocal for the posteriors (TF:1773-1778) is then formed once per (frame, state)
+            // instead of once per lane and row, and handed back to the state's lanes by quad
+            // broadcasts.
             constexpr int NV = MPL >= 4 ? 1 : (MPL == 2 ? 2 : 4);
             double sv[NV];
             {
@@ -631,28 +667,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
 #pragma unroll
                     for (int tt = 1; tt < TPS; tt++) tot[r] += e[tt][r];
                 }
-                if (MPL == 1) {
-#pragma unroll
-                    for (int r = 0; r < NV; r++) sv[r] = tot[r % 4];
-                } else {
-                    const bool o0 = (j & 1) != 0;
-                    double k0 = o0 ? tot[1] : tot[0], k1 = o0 ? tot[3] : tot[2];
-                    const double s0 = o0 ? tot[0] : tot[1], s1 = o0 ? tot[2] : tot[3];
-                    k0 += dpp_f64<DPP_QUAD_XOR1>(s0);
-                    k1 += dpp_f64<DPP_QUAD_XOR1>(s1);
-                    if (MPL == 2) {
-                        sv[0] = k0;
-                        sv[NV - 1] = k1;
-                    } else {
-                        const bool o1 = (j & 2) != 0;
-                        double kk = o1 ? k1 : k0;
-                        const double ss = o1 ? k0 : k1;
-                        kk += dpp_f64<DPP_QUAD_XOR2>(ss);
-                        if (MPL >= 8) kk += dpp_xor4_f64(kk);
-                        if (MPL >= 16) kk += dpp_f64<DPP_ROW_ROR8>(kk);
-                        sv[0] = kk;
-                    }
-                }
+                transposed_sums<MPL, NV>(tot, j, sv);
             }
             // rows held by this lane: rw = v-th held row; b is stored by the first lanes of the
             // state's group (one per row), everything else goes to the sink (cursor tables)
