@@ -857,11 +857,22 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         constexpr int SL = RD_THREADS / 128;
         const int e = tid & 127, half = tid >> 7;
         if (a.Pm > 0 && !(a.condg[gp] > a.cond_max)) {
-            double v = 0.0;
-            if (e < a.ES)
-                for (int p = half; p < a.Pm; p += SL)
-                    v += a.part_m[((size_t)p * a.NT * 16 + gp) * a.ES + e];
-            sh[tid] = v;
+            // four independent chains (fixed assignment of partials to chains: reproducible),
+            // so that the loads of a thread overlap
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            if (e < a.ES) {
+                const size_t pst = (size_t)a.NT * 16 * a.ES;
+                const double *pm = a.part_m + (size_t)gp * a.ES + e;
+                int p = half;
+                for (; p + 3 * SL < a.Pm; p += 4 * SL) {
+                    v0 += pm[(size_t)p * pst];
+                    v1 += pm[(size_t)(p + SL) * pst];
+                    v2 += pm[(size_t)(p + 2 * SL) * pst];
+                    v3 += pm[(size_t)(p + 3 * SL) * pst];
+                }
+                for (; p < a.Pm; p += SL) v0 += pm[(size_t)p * pst];
+            }
+            sh[tid] = (v0 + v1) + (v2 + v3);
             __syncthreads();
             if (tid < 128) {
                 double t = sh[tid];
