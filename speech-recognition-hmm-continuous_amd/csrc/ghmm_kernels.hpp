@@ -992,15 +992,34 @@ __device__ inline void mstep_state(int N, int M, int D, const double *__restrict
         for (int m = tid; m < M; m += nt) c[i * M + m] = num_c[i * M + m] / den_c[i];
     }
     __syncthreads();
-    if (tid == 0) {
-        double sum = 0.0;
-        for (int k = 0; k < M; k++) {
-            double v = c[i * M + k];
-            if (v < FLOOR) v = FLOOR;
-            c[i * M + k] = v;
-            sum += v;
+    // changing_zero_coef (TF:1338-1359): floor the weights, then renormalise by their sum taken
+    // in the reference's order (thread 0, from LDS: no global round trip per term)
+    {
+        const bool in_lds = lds_doubles >= M;
+        __shared__ double csum;
+        if (in_lds) {
+            for (int k = tid; k < M; k += nt) {
+                double v = c[i * M + k];
+                vs[k] = v < FLOOR ? FLOOR : v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double sum = 0.0;
+                for (int k = 0; k < M; k++) sum += vs[k];
+                csum = sum;
+            }
+            __syncthreads();
+            for (int k = tid; k < M; k += nt) c[i * M + k] = vs[k] / csum;
+        } else if (tid == 0) {
+            double sum = 0.0;
+            for (int k = 0; k < M; k++) {
+                double v = c[i * M + k];
+                if (v < FLOOR) v = FLOOR;
+                c[i * M + k] = v;
+                sum += v;
+            }
+            for (int k = 0; k < M; k++) c[i * M + k] /= sum;
         }
-        for (int k = 0; k < M; k++) c[i * M + k] /= sum;
     }
     __syncthreads();
     // det = product of the (floored) variances in order, then the inverses (TF:343-346);
