@@ -861,9 +861,9 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         const int XS = NE * 16; // >= 2*DP; XS*2 dwords = 32 (mod 64) for odd NE: conflict-free rows
         const int SZ = 16 * (XS + GW + N) + DP;
         double *fx = lds + (size_t)w * SZ, *ps = fx + 16 * XS, *gs = ps + 16 * GW, *ol = gs + 16 * N;
-        for (int k = l; k < DP; k += WAVE) ol[k] = k < D ? oglob[k] : 0.0;
-        for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
-            for (int col = l; col < XS; col += WAVE) fx[r * XS + col] = col == D ? 1.0 : 0.0;
+        // (the offset vector is read now and parked in LDS after the first stage's loads have
+        // been issued, so that the kernel's set-up runs under their HBM latency)
+        const double og_l = l < D ? oglob[l] : 0.0, og_h = l + WAVE < D ? oglob[l + WAVE < D ? l + WAVE : 0] : 0.0;
         // 16-byte pieces moved per stage: X 8*D, posteriors 8*GW, gamma 8*N; lane l takes
         // pieces l + 64u.  Bounds: 8*D <= 64*NE, 8*GW <= 64*2*CT, 8*N <= 64*2.  Surplus lanes
         // repeat the last piece, load and store alike (same value to the same place): no
@@ -914,8 +914,12 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
 #pragma unroll
             for (int u = 0; u < NGL; u++) rg[u] = gsrc[pcg[u]];
         };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (s0 < s1) fetch(s0);
+        if (l < DP) ol[l] = og_l;
+        if (l + WAVE < DP) ol[l + WAVE] = og_h;
+        for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
+            for (int col = l; col < XS; col += WAVE) fx[r * XS + col] = col == D ? 1.0 : 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (long long stg = s0; stg < s1; stg++) {
 #pragma unroll
             for (int u = 0; u < NXL; u++) {
