@@ -1258,7 +1258,8 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
     {
         kscope ks(ctx, GHMM_K_MSTEP);
         size_t md = (size_t)m->M * m->D;
-        int lds_doubles = md * 8 <= 56 * 1024 ? (int)md : 0; // + offsets and a reduction buffer: under 64 KB
+        // the state's variances + weights in LDS (+ offsets and a reduction buffer: under 64 KB)
+        int lds_doubles = (md + m->M) * 8 <= 56 * 1024 ? (int)(md + m->M) : 0;
         if (m->mfma_ok) {
             // M-step and matrix-core preparation of the new model in one launch
             m->epoch++;

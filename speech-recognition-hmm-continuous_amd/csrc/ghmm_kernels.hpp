@@ -980,6 +980,57 @@ __device__ inline void mstep_state(int N, int M, int D, const double *__restrict
         }
         logA[i * N + j] = v > 0.0 ? log(v) : -INFINITY;
     }
+    __shared__ double csum;
+    if (lds_doubles >= M * D + M) {
+        // The state's variances and weights live in LDS from here to the end (no global
+        // write-then-read between the steps).  den_c == 0: the state keeps what it had (TF:1935);
+        // its cov_matrix slot then holds INVERSE variances, which calc_det / inv_matrix
+        // (TF:343-346) treat like any other: reproduced.
+        double *vw = vs + (size_t)M * D;
+        const bool upd = den_c[i] != 0.0;
+        for (int k = tid; k < M * D; k += nt) {
+            const int g = i * M + k / D;
+            const size_t q = (size_t)i * M * D + k;
+            double v;
+            if (upd) {
+                mean[q] = num_mu[q] / num_c[g];
+                v = num_var[q] / num_c[g];
+                if (v < FLOOR) v = FLOOR;
+            } else {
+                v = inv_var[q];
+            }
+            vs[k] = v;
+        }
+        // changing_zero_coef (TF:1338-1359): floor the weights, renormalise by their sum taken
+        // in the reference's order
+        for (int m = tid; m < M; m += nt) {
+            const double cv = upd ? num_c[i * M + m] / den_c[i] : c[i * M + m];
+            vw[m] = cv < FLOOR ? FLOOR : cv;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int k = 0; k < M; k++) sum += vw[k];
+            csum = sum;
+        }
+        __syncthreads();
+        // det = product of the (floored) variances in order, then the inverses (TF:343-346)
+        for (int m = tid; m < M; m += nt) {
+            const int g = i * M + m;
+            const double cg = vw[m] / csum;
+            c[g] = cg;
+            const double *v = vs + (size_t)m * D;
+            double d = 1.0;
+            for (int k = 0; k < D; k++) d *= v[k];
+            det[g] = d;
+            const double den = norm2pi * sqrt(fabs(d));
+            wk[g] = cg / den;
+            logwk[g] = log(cg) - log(den);
+        }
+        for (int k = tid; k < M * D; k += nt) inv_var[(size_t)i * M * D + k] = 1.0 / vs[k];
+        return;
+    }
+    // states too large for LDS: the same steps through global memory
     if (den_c[i] != 0.0) {
         for (int k = tid; k < M * D; k += nt) {
             const int g = i * M + k / D;
@@ -992,49 +1043,20 @@ __device__ inline void mstep_state(int N, int M, int D, const double *__restrict
         for (int m = tid; m < M; m += nt) c[i * M + m] = num_c[i * M + m] / den_c[i];
     }
     __syncthreads();
-    // changing_zero_coef (TF:1338-1359): floor the weights, then renormalise by their sum taken
-    // in the reference's order (thread 0, from LDS: no global round trip per term)
-    {
-        const bool in_lds = lds_doubles >= M;
-        __shared__ double csum;
-        if (in_lds) {
-            for (int k = tid; k < M; k += nt) {
-                double v = c[i * M + k];
-                vs[k] = v < FLOOR ? FLOOR : v;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                double sum = 0.0;
-                for (int k = 0; k < M; k++) sum += vs[k];
-                csum = sum;
-            }
-            __syncthreads();
-            for (int k = tid; k < M; k += nt) c[i * M + k] = vs[k] / csum;
-        } else if (tid == 0) {
-            double sum = 0.0;
-            for (int k = 0; k < M; k++) {
-                double v = c[i * M + k];
-                if (v < FLOOR) v = FLOOR;
-                c[i * M + k] = v;
-                sum += v;
-            }
-            for (int k = 0; k < M; k++) c[i * M + k] /= sum;
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int k = 0; k < M; k++) {
+            double v = c[i * M + k];
+            if (v < FLOOR) v = FLOOR;
+            c[i * M + k] = v;
+            sum += v;
         }
+        for (int k = 0; k < M; k++) c[i * M + k] /= sum;
     }
     __syncthreads();
-    // det = product of the (floored) variances in order, then the inverses (TF:343-346);
-    // the state's M*D values go through LDS so that the serial product does not pay a
-    // global-memory round trip per factor
-    const double *src = inv_var + (size_t)i * M * D;
-    const bool staged = lds_doubles >= M * D;
-    if (staged) {
-        for (int k = tid; k < M * D; k += nt) vs[k] = src[k];
-        __syncthreads();
-        src = vs;
-    }
     for (int m = tid; m < M; m += nt) {
         const int g = i * M + m;
-        const double *v = staged ? src + (size_t)m * D : inv_var + (size_t)g * D;
+        const double *v = inv_var + (size_t)g * D;
         double d = 1.0;
         for (int k = 0; k < D; k++) d *= v[k];
         det[g] = d;
@@ -1042,9 +1064,10 @@ __device__ inline void mstep_state(int N, int M, int D, const double *__restrict
         wk[g] = c[g] / den;
         logwk[g] = log(c[g]) - log(den);
     }
+    __syncthreads(); // every determinant is taken before any variance is inverted in place
     for (int k = tid; k < M * D; k += nt) {
         const size_t q = (size_t)i * M * D + k;
-        inv_var[q] = 1.0 / (staged ? vs[k] : inv_var[q]);
+        inv_var[q] = 1.0 / inv_var[q];
     }
 }
 

@@ -283,6 +283,7 @@ def synth_case(G, N, M, D, lens, perturb=0.05, first=0, dense_A=False, seed=3):
     (2, 5, 3, [33, 20], True),
     (33, 2, 4, [50, 70], True),                                      # N > 16: one wave per utterance
     (10, 8, 39, [5000, 2999], False),                                # long utterances (reference cap: 500)
+    (2, 96, 80, [40, 33], False),                                    # a state too large for the M-step's LDS staging
 ])
 def test_estep_against_oracle(G, ctx, N, M, D, lens, dense):
     hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense)
