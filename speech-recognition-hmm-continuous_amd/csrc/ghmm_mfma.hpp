@@ -419,16 +419,16 @@ __device__ inline void exp_emis4(const v4d &x, double (&out)[4])
         k[q] = t - 0x1.8p52;
         r[q] = fma(-k[q], 6.93147180369123816490e-01, xc);
         r[q] = fma(-k[q], 1.90821492927058770002e-10, r[q]);
-        p[q] = 1.6059043836821613e-10;
+        p[q] = 2.08767569878680989792e-09; // 1/12!: |r| <= ln2/2, the next term is below 1.7e-16
     }
-    const double cf[12] = {2.08767569878680989792e-09, 2.50521083854417187751e-08,
-                           2.75573192239858906526e-07, 2.75573192239858906526e-06,
-                           2.48015873015873015873e-05, 1.98412698412698412698e-04,
-                           1.38888888888888888889e-03, 8.33333333333333333333e-03,
-                           4.16666666666666666667e-02, 1.66666666666666666667e-01,
-                           0.5,                        1.0};
+    const double cf[11] = {2.50521083854417187751e-08, 2.75573192239858906526e-07,
+                           2.75573192239858906526e-06, 2.48015873015873015873e-05,
+                           1.98412698412698412698e-04, 1.38888888888888888889e-03,
+                           8.33333333333333333333e-03, 4.16666666666666666667e-02,
+                           1.66666666666666666667e-01, 0.5,
+                           1.0};
 #pragma unroll
-    for (int t = 0; t < 12; t++)
+    for (int t = 0; t < 11; t++)
 #pragma unroll
         for (int q = 0; q < 4; q++) p[q] = fma(p[q], r[q], cf[t]);
 #pragma unroll
