@@ -1293,6 +1293,7 @@ extern "C" int ghmm_model_init(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
     HIP_TRY(hipMemsetAsync(ctx->part_dena, 0, (size_t)c->U * N * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->part_denc, 0, (size_t)c->U * N * 8, ctx->stream));
     ctx->slots = c->U;
+    ctx->loglik_pieces = false; // log P plays no part here: the zeroed loglik[] is what gets summed
     HIP_TRY(hipMemsetAsync(ctx->loglik, 0, (size_t)c->U * 8, ctx->stream));
     ghmm_stats *st = nullptr;
     if ((rc = ghmm_stats_create(ctx, N, M, D, &st))) return rc;
