@@ -6,14 +6,15 @@
 //                                        + (-1/2 sum_d mu'_d^2 inv_d)
 // so a tile of 16 frames x 16 Gaussians is a [16 x K] . [K x 16] product with
 // K = 2*DP (DP = D+1 rounded up to a multiple of 4), i.e. K/4 f64 MFMAs.  f64 MFMA
-// runs at the same 78.6 TFLOP/s as the f64 vector ALU on MI355X, but it leaves the
-// vector ALU free for exp()/normalisation and keeps operands out of VGPR traffic.
+// runs at the same 78.6 TFLOP/s as the f64 vector ALU on MI355X and never overlaps it on
+// a SIMD (measured): what it buys is issue slots (2 048 flops per
+// instruction) and operands straight from LDS.
 //
 // Cancellation: the expanded form loses eps * sum_d inv_d mu'_d^2 absolutely, so
-// (1) every tile of 16 Gaussians gets its own offset (the mean of its means) and
-// (2) tiles that still hold an ill-conditioned Gaussian (cond > COND_MAX, e.g. the
-// variance-floored "needle" components of SURVEY.md §7) are evaluated in the
-// reference's direct form (x-mu)*inv*(x-mu) by the same kernel.
+// (1) frames and means are taken relative to one offset near the data's centre (oglob) and
+// (2) a model that still holds an ill-conditioned Gaussian (cond > COND_MAX, e.g. the
+// variance-floored "needle" components of SURVEY.md §7) has the affected tiles evaluated in
+// the reference's direct form (x-mu)*inv*(x-mu) by k_emission_mfma.
 //
 // Fragment maps (cdna_hip_programming.md §3): lane l, A[i = l&15][k = l>>4],
 // B[k = l>>4][j = l&15], C/D reg r -> row (l>>4) + 4r, col l&15.
@@ -379,10 +380,10 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
 // Same computation as k_emission_mfma for the common, well-conditioned case (no
 // ill-conditioned Gaussian anywhere, Mp a power of two <= 64), built for 4 waves per SIMD: sixteen
 // waves per block (one block per CU) share the chunk's B fragments in LDS, every wave
-// keeps only x' = x - oglob of its 16 frames in a 5 KB slab (the squares are formed in
-// registers, one multiply per MFMA), and the kernel stays under 128 VGPRs.  While one
-// wave waits for the 64-cycle f64 matrix pipe, the other three run their epilogues
-// (exp, state sums, posteriors), so matrix pipe and vector ALU are busy together.
+// keeps x' = x - oglob of its 16 frames in a 5 KB slab and, where registers allow, as A
+// fragments (x', x'^2) for all of the frame tile's Gaussian tiles; the kernel stays under 128
+// VGPRs.  An f64 MFMA and vector-ALU work never overlap on a SIMD; the four
+// waves cover each other's LDS and HBM waits.
 //   - K steps, mixture padding and "posteriors wanted" are compile-time
 //   - the epilogue is branch-free: lanes without an output store to a sink
 //   - v / b_i is a reciprocal (hardware seed + two Newton steps) after an exact
@@ -744,10 +745,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
 //     num_c = S[.][D],  num_mu_d = S_d + oglob_d num_c,
 //     num_var_d = sum w (x_d - mu_d)^2 = S_{DP+d} - 2 mu'_d S_d + mu'_d^2 num_c   (old mean, TF:1720)
 // A = w^T (16 Gaussians x 4 frames), B = Fext (4 frames x 16 features).  One wave owns
-// CT x NE accumulator tiles and a contiguous range of frames; operands come straight
-// from HBM/L2 in 128-B row segments, prefetched one k-step ahead.  The four waves of
-// a block fold their tiles through LDS in wave order and the block writes ONE partial;
-// k_sum_partials adds the partials in block order (bitwise reproducible).
+// CT x NE accumulator tiles and a contiguous range of frames; operands are staged through
+// LDS (STAGED) or come straight from HBM/L2, prefetched a few k-steps ahead.  The four waves
+// of a block fold their tiles through LDS in wave order and the block writes ONE partial;
+// k_reduce_all adds the partials in a fixed order (bitwise reproducible).
 // a 64-bit value that is the same in every lane, moved to scalar registers
 __device__ inline long long uniform64(long long v)
 {
