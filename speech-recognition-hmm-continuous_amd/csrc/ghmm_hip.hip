@@ -2,7 +2,7 @@
 //
 // Host logic only: contexts, device buffers, launch geometry, HIP-event timing.
 // All arithmetic of the path happens in the kernels (ghmm_kernels.hpp,
-// ghmm_mfma.hpp).  No CPU fallback: without a gfx950 device every entry point that
+// ghmm_mfma.hpp, ghmm_pair.hpp).  No CPU fallback: without a gfx950 device every entry point that
 // needs one fails with GHMM_ERR_NODEVICE.
 #include "ghmm.h"
 
