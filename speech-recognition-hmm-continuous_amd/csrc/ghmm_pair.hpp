@@ -225,7 +225,7 @@ __device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool
                 *pbe = bt * (ct * fac);
             } else {
                 if (t < T - 1) rhon = sbt > 0.0 ? ct * rhon / sbt : 0.0;
-                *pbe = bt * rhon;
+                *pbe = bt > 0.0 ? bt * rhon : 0.0; // (a zero stays zero when rho has overflowed)
             }
             pbe -= dn;
         }

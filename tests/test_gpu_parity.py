@@ -368,6 +368,42 @@ def test_paired_scans_equal_the_reference_order(G, ctx, N, M, D, lens, dense, de
         o.close()
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_tiers_agree_on_random_shapes(G, ctx, seed):
+    """Seeded random shapes (states, mixtures, coefficients, ragged lengths down to one frame,
+    band-diagonal or dense A, transition band 0..3, linear or robust emission): the default tier
+    (matrix cores, paired scans) and the vector-ALU / reference-order tier give the same E-step."""
+    rng = np.random.default_rng(1000 + seed)
+    N, M, D = int(rng.integers(1, 21)), int(rng.integers(1, 10)), int(rng.integers(1, 41))
+    lens = [int(x) for x in rng.integers(1, 90, size=int(rng.integers(1, 7)))]
+    if seed % 4 == 0:
+        lens.append(0)
+    dense, delta, robust = bool(rng.integers(0, 2)), int(rng.integers(0, 4)), int(rng.integers(0, 2))
+    hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense, seed=seed)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    F = corpus.frames
+    out = {}
+    try:
+        ctx.set_option(G.OPT_DELTA, delta)
+        ctx.set_option(G.OPT_ROBUST, robust)
+        for tier in (1, 0):
+            ctx.set_option(G.OPT_KERNELS, tier)
+            stats = ctx.stats(N, M, D)
+            ctx.estep(model, corpus, stats)
+            out[tier] = dict(stats=stats.download(), gamma=ctx.fetch(G.BUF_GAMMA, (F, N)),
+                             beta=ctx.fetch(G.BUF_BETA, (F, N)), ll=ctx.fetch(G.BUF_LOGLIK, (len(lens),)))
+            stats.close()
+    finally:
+        ctx.set_option(G.OPT_KERNELS, 0)
+        ctx.set_option(G.OPT_DELTA, 1)
+        ctx.set_option(G.OPT_ROBUST, 0)
+    what = f"N={N} M={M} D={D} lens={list(lens)} dense={dense} delta={delta} robust={robust}"
+    for k in ("ll", "gamma", "beta", "stats"):
+        assert_close(out[0][k], out[1][k], rtol=1e-9, what=f"{k} ({what})")
+    for o in (model, corpus):
+        o.close()
+
+
 def test_beta_on_demand_follows_the_model(G, ctx):
     """ghmm_estep leaves beta^ out; ghmm_fetch forms it from the E-step's alpha^ / W while the model
     is unchanged, and refuses once ghmm_mstep has replaced the parameters they belong to."""
