@@ -1142,7 +1142,8 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         kscope ks(ctx, GHMM_K_MIXSTATS);
         hipLaunchKernelGGL(k_mixstats, dim3((unsigned)P, (unsigned)NB), dim3(MS_THREADS), lds,
                            ctx->stream, N, M, D, c->F, fpb, FS, c->X, ctx->gamma, ctx->post, m->mean,
-                           ctx->part_mu, ctx->part_var, only_if, m->epoch);
+                           ctx->part_mu, ctx->part_var, only_if, m->epoch,
+                           (mfma && G <= MS_MAXG) ? m->condg : (const double *)nullptr, m->Mp, COND_MAX);
         if ((rc = launch_ok("k_mixstats"))) return rc;
     }
     {

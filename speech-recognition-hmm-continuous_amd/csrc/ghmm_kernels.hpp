@@ -723,6 +723,7 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
 // partial sums; k_reduce adds them in block order (bitwise reproducible).
 constexpr int MS_THREADS = 256;
 constexpr int MS_EPT = 8;
+constexpr int MS_MAXG = 4096; // Gaussians the compact list of k_mixstats can hold
 constexpr int MS_FS = 32; // frames staged per pass (fewer when a wide tile would not fit LDS)
 
 __global__ void __launch_bounds__(MS_THREADS)
@@ -730,31 +731,53 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
            const double *__restrict__ X, const double *__restrict__ gamma,
            const double *__restrict__ post, const double *__restrict__ mean,
            double *__restrict__ part_mu, double *__restrict__ part_var,
-           const int *__restrict__ only_if, int epoch)
+           const int *__restrict__ only_if, int epoch, const double *__restrict__ condg = nullptr,
+           int Mp = 0, double cond_max = 0.0)
 {
     extern __shared__ double lds[];
+    __shared__ int fl[MS_MAXG]; // condg != nullptr: the ill-conditioned Gaussians, in index order
+    __shared__ int nfl;
     if (only_if && only_if[0] != epoch) return; // matrix-core tier: nothing is ill-conditioned
     const int G = N * M, D1 = D + 1;
-    const long long E = (long long)G * D1;
     const int tid = threadIdx.x;
+    // Behind the matrix-core kernel only the ill-conditioned Gaussians' sums are used
+    // (k_reduce_all): the element space shrinks to those Gaussians (a handful of variance-
+    // floored components in a typical training run), every block builds the same list.
+    int GE = G;
+    if (condg) {
+        if (tid == 0) {
+            int n = 0;
+            for (int g = 0; g < G; g++)
+                if (condg[(g / M) * Mp + g % M] > cond_max) fl[n++] = g;
+            nfl = n;
+        }
+        __syncthreads();
+        GE = nfl;
+    }
+    const long long E = (long long)G * D1, EE = (long long)GE * D1; // real / compact element space
     const long long e0 = (long long)blockIdx.y * (MS_THREADS * MS_EPT);
-    const long long e1 = (e0 + MS_THREADS * MS_EPT < E) ? e0 + MS_THREADS * MS_EPT : E;
+    if (e0 >= EE) return;
+    const long long e1 = (e0 + MS_THREADS * MS_EPT < EE) ? e0 + MS_THREADS * MS_EPT : EE;
     const int g0 = (int)(e0 / D1);
-    const int g1 = (int)((e1 - 1) / D1); // inclusive
+    const int g1 = (int)((e1 - 1) / D1); // inclusive (compact indices when condg)
     const int GW = g1 - g0 + 1;
     double *xs = lds;                // [FS][D1]
     double *ws = lds + FS * D1;      // [FS][GW]
+    auto real = [&](int gc) { return condg ? fl[gc] : gc; };
 
     int gx[MS_EPT], dx[MS_EPT];
+    long long eo[MS_EPT]; // where the element's sums go (real layout)
     double mu[MS_EPT], acc_mu[MS_EPT], acc_var[MS_EPT];
 #pragma unroll
     for (int k = 0; k < MS_EPT; k++) {
         long long e = e0 + tid + (long long)k * MS_THREADS;
         bool ok = e < e1;
-        int g = ok ? (int)(e / D1) : g0;
-        int d = ok ? (int)(e - (long long)g * D1) : D;
-        gx[k] = g - g0;
+        int gc = ok ? (int)(e / D1) : g0;
+        int d = ok ? (int)(e - (long long)gc * D1) : D;
+        const int g = real(gc);
+        gx[k] = gc - g0;
         dx[k] = d;
+        eo[k] = ok ? (long long)g * D1 + d : -1;
         mu[k] = (ok && d < D) ? mean[(size_t)g * D + d] : 0.0;
         acc_mu[k] = 0.0;
         acc_var[k] = 0.0;
@@ -770,7 +793,7 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
         }
         for (int k = tid; k < nf * GW; k += MS_THREADS) {
             int r = k / GW, gl = k - r * GW;
-            int g = g0 + gl;
+            int g = real(g0 + gl);
             ws[k] = gamma[(fs + r) * N + g / M] * post[(fs + r) * G + g];
         }
         __syncthreads();
@@ -786,13 +809,11 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
         }
     }
 #pragma unroll
-    for (int k = 0; k < MS_EPT; k++) {
-        long long e = e0 + tid + (long long)k * MS_THREADS;
-        if (e < e1) {
-            part_mu[(size_t)blockIdx.x * E + e] = acc_mu[k];
-            part_var[(size_t)blockIdx.x * E + e] = acc_var[k];
+    for (int k = 0; k < MS_EPT; k++)
+        if (eo[k] >= 0) {
+            part_mu[(size_t)blockIdx.x * E + eo[k]] = acc_mu[k];
+            part_var[(size_t)blockIdx.x * E + eo[k]] = acc_var[k];
         }
-    }
 }
 
 // ------------------------------------------------------------------- reduce

@@ -308,20 +308,23 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                 for (int s = 0; s < KS; s++)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[4 * s], Wt[s * 64], acc, 0, 0, 0);
             } else {
-                // ill-conditioned tile: the reference's own form, TF:1829-1832
+                // ill-conditioned tile: the reference's own form, TF:1829-1832 (summed over d in
+                // its order; the Gaussian's mean and inverse variance are read once per d for
+                // the lane's four frames)
+                double q4[4] = {0.0, 0.0, 0.0, 0.0};
+                const int gq = gm >= 0 ? gm : 0;
+                const double *mu = mean + (size_t)gq * D, *iv = inv_var + (size_t)gq * D;
+                const double *xf = xw + kq * XS;
+                for (int d = 0; d < D; d++) {
+                    const double md = mu[d] - oglob[d], id = iv[d];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    double q = 0.0;
-                    if (gm >= 0) {
-                        const double *xf = xw + (kq + 4 * r) * XS;
-                        const double *mu = mean + (size_t)gm * D, *iv = inv_var + (size_t)gm * D;
-                        for (int d = 0; d < D; d++) {
-                            double dif = xf[d] - (mu[d] - oglob[d]);
-                            q += dif * iv[d] * dif;
-                        }
+                    for (int r = 0; r < 4; r++) {
+                        const double dif = xf[4 * r * XS + d] - md;
+                        q4[r] += dif * id * dif;
                     }
-                    acc[r] = -0.5 * q;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = gm >= 0 ? -0.5 * q4[r] : 0.0;
             }
             double v[4];
 #pragma unroll
