@@ -1088,6 +1088,13 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     // frame-block partials: enough blocks to fill the chip a few times over, few
     // enough that the partial sums stay small next to the frame data
     long long P = ctx->partials > 0 ? ctx->partials : (2LL * ctx->cus + NB - 1) / NB;
+    if (mfma && ctx->partials <= 0 && G <= MS_MAXG) {
+        // behind the matrix-core kernel this one only sees the few ill-conditioned Gaussians
+        // (one block of elements): parallelism has to come from the frame axis
+        P = 4LL * ctx->cus;
+        const long long cap = (256LL << 20) / (E * 16);
+        if (P > cap) P = cap;
+    }
     if (P < 1) P = 1;
     // frames staged through LDS per pass: x[FS][D+1] + w[FS][GW], GW = Gaussians that a
     // batch of 256*EPT elements can touch; keep the tile under 48 KB
