@@ -96,6 +96,11 @@ struct ghmm_model {
     double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *logwkp = nullptr, *condp = nullptr;
     double *oglob = nullptr, *condg = nullptr;
     int *gmap = nullptr, *anyflag = nullptr;
+    // per-tile offsets of the expanded form (ghmm_mfma.hpp): otile[NT][DP] the offset itself,
+    // dtile = otile - oglob, tshift[NT] = the tile has its own offset; condt = conditioning
+    // relative to the tile's offset; sflag: like anyflag, for the statistics (global offset)
+    double *otile = nullptr, *dtile = nullptr, *condt = nullptr;
+    int *tshift = nullptr, *sflag = nullptr, *tnext = nullptr; // tnext: the choice for the next preparation
     bool banded = false; // A as last set from the host has a_ij = 0 unless j = i or i + 1
     int epoch = 0; // preparation count; anyflag[0] == epoch: this model holds an ill-conditioned Gaussian
     int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
@@ -404,10 +409,13 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
         m->epoch++;
         hipLaunchKernelGGL(k_prepare_offsets, dim3((unsigned)(m->NT + m->D)), dim3(64), 0, ctx->stream,
                            m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob);
+        hipLaunchKernelGGL(k_prepare_tiles, dim3((unsigned)m->NT), dim3(64), 0, ctx->stream, m->N, m->M,
+                           m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var, m->oglob, m->otile, m->tnext);
         hipLaunchKernelGGL(k_prepare_mfma, dim3((unsigned)(m->NT * 16)), dim3(64), 0,
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
-                           m->wk, m->logwk, m->offs, m->oglob, m->Wm, m->wkp, m->logwkp, m->gmap,
-                           m->condp, m->condg, m->anyflag, m->epoch);
+                           m->wk, m->logwk, m->otile, m->tnext, m->oglob, m->Wm, m->wkp, m->logwkp,
+                           m->gmap, m->condt, m->condg, m->anyflag, m->sflag, m->epoch, m->dtile,
+                           m->tshift);
     }
     return launch_ok("k_prepare_mfma");
 }
@@ -455,10 +463,19 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
                 (rc = dev_alloc(&m->condp, (size_t)m->NT * 16)) ||
                 (rc = dev_alloc(&m->gmap, (size_t)m->NT * 16)) ||
                 (rc = dev_alloc(&m->condg, (size_t)m->NT * 16)) ||
-                (rc = dev_alloc(&m->oglob, (size_t)m->DP)) || (rc = dev_alloc(&m->anyflag, 1))) {
+                (rc = dev_alloc(&m->oglob, (size_t)m->DP)) || (rc = dev_alloc(&m->anyflag, 1)) ||
+                (rc = dev_alloc(&m->otile, (size_t)m->NT * m->DP)) || (rc = dev_alloc(&m->dtile, (size_t)m->NT * m->DP)) ||
+                (rc = dev_alloc(&m->condt, (size_t)m->NT * 16)) || (rc = dev_alloc(&m->tshift, (size_t)m->NT)) ||
+                (rc = dev_alloc(&m->sflag, 1)) || (rc = dev_alloc(&m->tnext, (size_t)m->NT))) {
                 ghmm_model_destroy(ctx, m);
                 return rc;
             }
+            (void)hipMemset(m->dtile, 0, (size_t)m->NT * m->DP * 8);
+            (void)hipMemset(m->otile, 0, (size_t)m->NT * m->DP * 8);
+            (void)hipMemset(m->tshift, 0, (size_t)m->NT * sizeof(int));
+            (void)hipMemset(m->condt, 0, (size_t)m->NT * 16 * 8);
+            (void)hipMemset(m->sflag, 0, sizeof(int));
+            (void)hipMemset(m->tnext, 0, (size_t)m->NT * sizeof(int));
             // statistics kernel: NE feature tiles of 16 over [x', 1, x'^2]; CT Gaussian tiles
             // per wave so that CT*NE accumulator tiles (8 VGPRs each) stay near 200 VGPRs
             m->NE = (2 * m->DP + 15) / 16;
@@ -480,7 +497,7 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
     }
     void *bufs[] = {m->A,  m->c,    m->mean, m->inv_var, m->det,   m->wk,    m->logwk, m->logA,
                     m->Wm, m->offs, m->wkp,  m->condp,   m->gmap,  m->oglob, m->condg, m->anyflag,
-                    m->logwkp};
+                    m->logwkp, m->otile, m->dtile, m->condt, m->tshift, m->sflag, m->tnext};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete m;
@@ -773,7 +790,8 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const int chunks = (m->NT + m->TC - 1) / m->TC;
         const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
                              (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
-                             (size_t)m->TC * 16 * 32; // wk + cursor tables
+                             (size_t)m->TC * 16 * 32 + // wk + cursor tables
+                             (size_t)m->TC * (m->DP + 1) * 8; // per-tile offsets
         long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
         if (gxs > ctx->cus) gxs = ctx->cus;
         kscope ks(ctx, GHMM_K_EMISSION);
@@ -787,7 +805,8 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         hipLaunchKernelGGL((k_emission_sched<20, MP, 2>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,  \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->logwkp, m->gmap, ctx->b,       \
-                           (double *)nullptr, ctx->sink, m->anyflag, m->epoch);                   \
+                           (double *)nullptr, ctx->sink, m->anyflag, m->epoch, m->dtile,          \
+                           m->tshift);                                                            \
     } while (0)
         switch (m->Mp) {
         case 1: GHMM_EML(1, 0); break;
@@ -817,7 +836,8 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const bool sched = (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
         const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
                              (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
-                             (size_t)m->TC * 16 * 32; // wk + cursor tables
+                             (size_t)m->TC * 16 * 32 + // wk + cursor tables
+                             (size_t)m->TC * (m->DP + 1) * 8; // per-tile offsets
         long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
         if (gxs > ctx->cus) gxs = ctx->cus;
         {
@@ -834,7 +854,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,   \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap, ctx->b, post,     \
-                           ctx->sink, m->anyflag, m->epoch);                                      \
+                           ctx->sink, m->anyflag, m->epoch, m->dtile, m->tshift);                 \
     } while (0)
 #define GHMM_EMS2(MP)                                                                             \
     do {                                                                                          \
@@ -854,8 +874,8 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
             hipLaunchKernelGGL(k_emission_mfma, dim3((unsigned)gx, (unsigned)chunks),
                                dim3(EM_WAVES * WAVE), m->em_lds, ctx->stream, m->N, m->M, m->Mp, m->D,
                                m->DP, m->NT, m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap,
-                               m->condg, m->mean, m->inv_var, ctx->b, post,
-                               sched ? m->anyflag : (const int *)nullptr, m->epoch);
+                               m->condt, m->mean, m->inv_var, ctx->b, post,
+                               sched ? m->anyflag : (const int *)nullptr, m->epoch, m->tshift, m->dtile);
         }
         ctx->b_is_log = false;
         return launch_ok("k_emission_mfma");
@@ -1111,7 +1131,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     fpb = ((fpb + FS - 1) / FS) * FS;
     if (fpb < FS) fpb = FS;
     P = c->F > 0 ? (c->F + fpb - 1) / fpb : 0;
-    const int *only_if = mfma ? m->anyflag : nullptr;
+    const int *only_if = mfma ? m->sflag : nullptr; // statistics: conditioning around the global offset
     if (P > 0) {
         size_t need = (size_t)P * (size_t)E;
         if ((rc = dev_grow(&ctx->part_mu, &ctx->cap_pmu, need))) return rc;
@@ -1164,12 +1184,15 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         ra.NT = m->NT; ra.DP = m->DP; ra.ES = m->NE * 16;
         ra.part_m = ctx->part_m; ra.condg = m->condg; ra.oglob = m->oglob; ra.mean = m->mean;
         ra.gmap = m->gmap; ra.cond_max = COND_MAX;
+        ra.otile = ra.Pm > 0 ? m->otile : nullptr;
+        ra.tnext = m->tnext;
         ra.part_xi = ctx->part_xi; ra.part_dena = ctx->part_dena; ra.part_denc = ctx->part_denc;
         ra.loglik = ctx->loglik; ra.stats = s->v;
         if (mfma && c->F == 0) ra.P1 = 0; // nothing accumulated: every sum is empty
         const int NGb = ra.Pm > 0 ? m->NT * 16 : G;
         kscope ks(ctx, GHMM_K_REDUCE);
-        hipLaunchKernelGGL(k_reduce_all, dim3((unsigned)(NGb + N * N + 2 * N + 1)), dim3(RD_THREADS), 0,
+        const int tile_blocks = ra.otile ? m->NT : 0; // the next model's tile offsets
+        hipLaunchKernelGGL(k_reduce_all, dim3((unsigned)(NGb + N * N + 2 * N + 1 + tile_blocks)), dim3(RD_THREADS), 0,
                            ctx->stream, ra);
     }
     return launch_ok("k_reduce_all");
@@ -1275,7 +1298,8 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
                                ((size_t)lds_doubles + m->DP + MSF_THREADS) * 8, ctx->stream, m->N, m->M, m->D, s->v,
                                pow(2.0 * M_PI, m->D / 2.0), m->A, m->c, m->mean, m->inv_var, m->det, m->wk,
                                m->logwk, m->logA, lds_doubles, m->Mp, m->NT, m->DP, m->oglob, m->Wm, m->wkp,
-                               m->logwkp, m->gmap, m->condg, m->anyflag, m->epoch);
+                               m->logwkp, m->gmap, m->condg, m->anyflag, m->epoch, m->otile, m->tnext,
+                               m->condt, m->dtile, m->tshift, m->sflag);
             return launch_ok("k_mstep_mfma");
         }
         hipLaunchKernelGGL(k_mstep, dim3((unsigned)m->N), dim3(MS2_THREADS), (size_t)lds_doubles * 8,

@@ -764,6 +764,7 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
     double *xs = lds;                // [FS][D1]
     double *ws = lds + FS * D1;      // [FS][GW]
     auto real = [&](int gc) { return condg ? fl[gc] : gc; };
+    const int kmax = (int)((e1 - e0 + MS_THREADS - 1) / MS_THREADS); // element slots in use per thread
 
     int gx[MS_EPT], dx[MS_EPT];
     long long eo[MS_EPT]; // where the element's sums go (real layout)
@@ -799,13 +800,14 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
         __syncthreads();
         for (int r = 0; r < nf; r++) {
 #pragma unroll
-            for (int k = 0; k < MS_EPT; k++) {
-                double w = ws[r * GW + gx[k]];
-                double x = xs[r * D1 + dx[k]];
-                acc_mu[k] += w * x;
-                double dif = x - mu[k];
-                acc_var[k] += w * (dif * dif);
-            }
+            for (int k = 0; k < MS_EPT; k++)
+                if (k < kmax) { // block-uniform: a short element range leaves the later slots empty
+                    double w = ws[r * GW + gx[k]];
+                    double x = xs[r * D1 + dx[k]];
+                    acc_mu[k] += w * x;
+                    double dif = x - mu[k];
+                    acc_var[k] += w * (dif * dif);
+                }
         }
     }
 #pragma unroll
@@ -859,6 +861,10 @@ struct reduce_args {
     // log P in pieces (ghmm_pair.hpp): -sum log c_t per slot and log alpha^_{T-1}(N-1) per utterance;
     // nullptr: loglik[u] is complete
     const double *lpart, *logk;
+    // per-tile offsets of the expanded form for the NEXT model (ghmm_mfma.hpp): chosen here from
+    // the model the statistics were taken with; nullptr: tier not in use
+    double *otile;
+    int *tnext;
     double *stats;
 };
 
@@ -961,7 +967,7 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         for (int u = tid; u < a.S; u += RD_THREADS) v += a.part_denc[pden_at(u, i, a.S)];
         v = block_sum_fixed(v, sh);
         if (tid == 0) den_c[i] = v;
-    } else {
+    } else if (q == N * N + 2 * N) {
         if (a.lpart) {
             for (int u = tid; u < a.S; u += RD_THREADS) v += a.lpart[u];
             for (int u = tid; u < U; u += RD_THREADS) v += a.logk[u];
@@ -972,6 +978,27 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         if (tid == 0) {
             num_var[(size_t)G * D] = v;            // loglik
             num_var[(size_t)G * D + 1] = (double)U; // n_utt
+        }
+    } else if (a.otile) {
+        // offset of the expanded form for tile t of the NEXT model: the mean of the tile's worst-
+        // conditioned Gaussian if one exceeds the bound (first maximum), else the global offset
+        const int t = q - (N * N + 2 * N + 1);
+        if (t < a.NT) {
+            int w = -1;
+            double best = a.cond_max;
+            for (int k = 0; k < 16; k++) {
+                const double cv = a.condg[t * 16 + k];
+                if (cv > best) {
+                    best = cv;
+                    w = k;
+                }
+            }
+            if (tid == 0) a.tnext[t] = w >= 0 ? 1 : 0;
+            if (w >= 0) {
+                const int g = a.gmap[t * 16 + w];
+                for (int d = tid; d < a.DP; d += RD_THREADS)
+                    a.otile[(size_t)t * a.DP + d] = (d < D && g >= 0) ? a.mean[(size_t)g * D + d] : 0.0;
+            }
         }
     }
 }

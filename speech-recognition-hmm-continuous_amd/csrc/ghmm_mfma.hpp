@@ -67,6 +67,56 @@ k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__r
     }
 }
 
+// Offset of the expanded form per tile.  A variance-floored component (EM from the reference's
+// initial model produces a few within two iterations: every variance at 1e-5, cond ~ 1e7
+// around the data's centre) is harmless around ITS OWN mean, and so are its 15 neighbours
+// (inverse variances ~ 1): a tile that holds a Gaussian with cond > COND_MAX takes the mean of its
+// worst Gaussian as offset.  tile_offset_choice: one wave; cond[16] of the tile's Gaussians
+// (padding: 0) -> index of the worst one, or -1 to keep the global offset.  First maximum wins,
+// so that every caller agrees.
+__device__ inline int tile_offset_choice(const double *cond16)
+{
+    int w = -1;
+    double best = COND_MAX;
+    for (int k = 0; k < 16; k++)
+        if (cond16[k] > best) {
+            best = cond16[k];
+            w = k;
+        }
+    return w;
+}
+
+// ghmm_model_set path: the choice from the model itself.  tnext / otile: what the next
+// preparation will use (k_prepare_mfma right behind this kernel).
+__global__ void __launch_bounds__(64)
+k_prepare_tiles(int N, int M, int D, int Mp, int NT, int DP, const double *__restrict__ mean,
+                const double *__restrict__ inv_var, const double *__restrict__ oglob,
+                double *__restrict__ otile, int *__restrict__ tnext)
+{
+    __shared__ double cond16[16];
+    const int c = blockIdx.x, t = threadIdx.x;
+    for (int k = 0; k < 16; k++) {
+        const int gp = c * 16 + k, i = gp / Mp, m = gp % Mp;
+        double v = 0.0;
+        if (i < N && m < M)
+            for (int d = t; d < D; d += 64) {
+                const size_t q = ((size_t)i * M + m) * D + d;
+                const double mu = mean[q] - oglob[d];
+                v += mu * mu * inv_var[q];
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (t == 0) cond16[k] = v;
+    }
+    __syncthreads();
+    const int w = tile_offset_choice(cond16);
+    if (t == 0) tnext[c] = w >= 0 ? 1 : 0;
+    if (w >= 0) {
+        const int gp = c * 16 + w, g = (gp / Mp) * M + gp % Mp;
+        for (int d = t; d < DP; d += 64) otile[(size_t)c * DP + d] = d < D ? mean[(size_t)g * D + d] : 0.0;
+    }
+}
+
 // One 64-thread block per padded Gaussian gp = 16*c + j (state gp / Mp, mixture gp % Mp),
 // threads over the coefficient index.
 //   Wm[c][s][lane]  B fragments in lane order: row kk = 4s + (lane>>4), col lane&15
@@ -77,11 +127,12 @@ k_prepare_offsets(int N, int M, int D, int Mp, int NT, int DP, const double *__r
 __global__ void __launch_bounds__(64)
 k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__restrict__ mean,
                const double *__restrict__ inv_var, const double *__restrict__ wk,
-               const double *__restrict__ logwk, const double *__restrict__ offs,
-               const double *__restrict__ oglob, double *__restrict__ Wm, double *__restrict__ wkp,
-               double *__restrict__ logwkp, int *__restrict__ gmap,
-               double *__restrict__ condp, double *__restrict__ condg, int *__restrict__ anyflag,
-               int epoch)
+               const double *__restrict__ logwk, const double *__restrict__ otile,
+               const int *__restrict__ tnext, const double *__restrict__ oglob,
+               double *__restrict__ Wm, double *__restrict__ wkp, double *__restrict__ logwkp,
+               int *__restrict__ gmap, double *__restrict__ condt, double *__restrict__ condg,
+               int *__restrict__ anyflag, int *__restrict__ sflag, int epoch,
+               double *__restrict__ dtile, int *__restrict__ tshift)
 {
     __shared__ double sh0[64], sh1[64];
     const int gp = blockIdx.x, t = threadIdx.x;
@@ -90,17 +141,20 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
     const bool real = (i < N) && (m < M);
     const int g = real ? i * M + m : -1;
     double *Wc = Wm + (size_t)c * KS * 64;
+    const bool shifted = tnext[c] != 0; // this tile has its own offset (k_prepare_tiles / k_reduce_all)
     double c0 = 0.0, cg = 0.0;
     for (int d = t; d < DP; d += 64) {
         double bc = 0.0, ac = 0.0;
         if (real && d < D) {
             const double mraw = mean[(size_t)g * D + d], iv = inv_var[(size_t)g * D + d];
-            const double mu = mraw - oglob[d], mt = mraw - offs[(size_t)c * DP + d];
-            bc = mu * iv;
+            const double mu = mraw - oglob[d];
+            const double mt = mraw - (shifted ? otile[(size_t)c * DP + d] : oglob[d]);
+            bc = mt * iv;
             ac = -0.5 * iv;
             cg += mu * mu * iv;
             c0 += mt * mt * iv;
         }
+        if (j == 0) dtile[(size_t)c * DP + d] = (shifted && d < D) ? otile[(size_t)c * DP + d] - oglob[d] : 0.0;
         if (d != D) Wc[(d >> 2) * 64 + (d & 3) * 16 + j] = bc;
         const int k2 = DP + d;
         Wc[(k2 >> 2) * 64 + (k2 & 3) * 16 + j] = ac;
@@ -117,17 +171,20 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
     }
     if (t == 0) {
         cg = sh0[0];
+        c0 = sh1[0];
         gmap[gp] = g;
         wkp[gp] = real ? wk[g] : 0.0;
         logwkp[gp] = real ? logwk[g] : -1.0e300; // padding never wins a max, exp() of it is 0
-        Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0; // multiplies the constant 1
-        condp[gp] = real ? sh1[0] : 0.0;
-        condg[gp] = real ? cg : 0.0;
+        Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * c0 : 0.0; // multiplies the constant 1
+        condt[gp] = real ? c0 : 0.0; // around the tile's offset: what the emission kernels go by
+        condg[gp] = real ? cg : 0.0; // around the global offset: what the statistics go by
+        if (j == 0) tshift[c] = shifted ? 1 : 0;
         // some Gaussian too ill-conditioned for the expanded forms: k_emission_mfma's direct
-        // form and the vector-ALU k_mixstats then take over for it
-        // (anyflag[0] == the model's preparation count means "flagged now": nothing has to
+        // form (anyflag) / the vector-ALU k_mixstats (sflag) then take over for it
+        // (flag[0] == the model's preparation count means "flagged now": nothing has to
         // clear it, every writer of one preparation stores the same value)
-        if (real && cg > COND_MAX) anyflag[0] = epoch;
+        if (real && c0 > COND_MAX) anyflag[0] = epoch;
+        if (real && cg > COND_MAX) sflag[0] = epoch;
     }
 }
 
@@ -146,7 +203,9 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
              double *__restrict__ logwk, double *__restrict__ logA, int lds_doubles, int Mp, int NT,
              int DP, double *__restrict__ oglob, double *__restrict__ Wm, double *__restrict__ wkp,
              double *__restrict__ logwkp, int *__restrict__ gmap, double *__restrict__ condg,
-             int *__restrict__ anyflag, int epoch)
+             int *__restrict__ anyflag, int epoch, const double *__restrict__ otile,
+             const int *__restrict__ tnext, double *__restrict__ condt, double *__restrict__ dtile,
+             int *__restrict__ tshift, int *__restrict__ sflag)
 {
     extern __shared__ double vs[]; // [lds_doubles] staging of mstep_state | og[DP] | red[MSF_THREADS]
     double *og = vs + lds_doubles, *red = og + DP;
@@ -194,28 +253,41 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
         const bool real = (ii < N) && (m < M);
         const int g = real ? ii * M + m : -1;
         double *Wc = Wm + (size_t)ct * KS * 64;
-        double cg = 0.0;
+        // the tile's own offset (chosen by k_reduce_all from the model before this M-step: a
+        // collapsed component does not move any more) or the data's centre
+        const bool shifted = tnext[ct] != 0;
+        double cg = 0.0, c0 = 0.0;
         for (int d = l; d < DP; d += 64) {
-            double bc = 0.0, ac = 0.0;
+            double bc = 0.0, ac = 0.0, dt = 0.0;
+            if (d < D) dt = shifted ? otile[(size_t)ct * DP + d] - og[d] : 0.0;
             if (real && d < D) {
                 const double mu = mean[(size_t)g * D + d] - og[d], iv = inv_var[(size_t)g * D + d];
-                bc = mu * iv;
+                const double mt = mu - dt;
+                bc = mt * iv;
                 ac = -0.5 * iv;
                 cg += mu * mu * iv;
+                c0 += mt * mt * iv;
             }
             if (d != D) Wc[(d >> 2) * 64 + (d & 3) * 16 + j] = bc;
             const int k2 = DP + d;
             Wc[(k2 >> 2) * 64 + (k2 & 3) * 16 + j] = ac;
+            dtile[(size_t)ct * DP + d] = dt; // every Gaussian of the tile writes the same values
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cg += __shfl_xor(cg, o, 64);
+        for (int o = 32; o > 0; o >>= 1) {
+            cg += __shfl_xor(cg, o, 64);
+            c0 += __shfl_xor(c0, o, 64);
+        }
         if (l == 0) {
             gmap[gp] = g;
             wkp[gp] = real ? wk[g] : 0.0;
             logwkp[gp] = real ? logwk[g] : -1.0e300;
-            Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * cg : 0.0;
+            Wc[(D >> 2) * 64 + (D & 3) * 16 + j] = real ? -0.5 * c0 : 0.0;
             condg[gp] = real ? cg : 0.0;
-            if (real && cg > COND_MAX) anyflag[0] = epoch;
+            condt[gp] = real ? c0 : 0.0;
+            tshift[ct] = shifted ? 1 : 0;
+            if (real && c0 > COND_MAX) anyflag[0] = epoch;
+            if (real && cg > COND_MAX) sflag[0] = epoch;
         }
     }
 }
@@ -236,7 +308,7 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
                 const int *__restrict__ gmap, const double *__restrict__ condg,
                 const double *__restrict__ mean, const double *__restrict__ inv_var,
                 double *__restrict__ b, double *__restrict__ post, const int *__restrict__ only_if,
-                int epoch)
+                int epoch, const int *__restrict__ tshift, const double *__restrict__ dtile)
 {
     extern __shared__ double lds[];
     if (only_if && only_if[0] != epoch) return; // k_emission_sched has done the job
@@ -300,13 +372,25 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
             const int gp = (c0 + ct) * 16 + j;
             const double wkj = wkp[gp];
             const int gm = gmap[gp];
+            // condg here = conditioning around the TILE's offset (the global one, or the mean of
+            // the tile's variance-floored component: dtile holds the difference)
             const bool flagged = __any(condg[gp] > COND_MAX);
             v4d acc = {0.0, 0.0, 0.0, 0.0};
-            if (!flagged) {
+            if (!flagged && tshift[c0 + ct] == 0) {
                 const double *Wt = Wl + (size_t)ct * KS * 64 + l;
 #pragma unroll 4
                 for (int s = 0; s < KS; s++)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[4 * s], Wt[s * 64], acc, 0, 0, 0);
+            } else if (!flagged) {
+                // the tile's own offset: x'' = x' - (offset - oglob), squares formed here
+                const double *Wt = Wl + (size_t)ct * KS * 64 + l;
+                const double *dq = dtile + (size_t)(c0 + ct) * DP + kq;
+                const int Q = KS / 2;
+                for (int s = 0; s < Q; s++) {
+                    const double x1 = xr[4 * s] - dq[4 * s];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, Wt[s * 64], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1 * x1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                }
             } else {
                 // ill-conditioned tile: the reference's own form, TF:1829-1832 (summed over d in
                 // its order; the Gaussian's mean and inverse variance are read once per d for
@@ -487,7 +571,8 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                  const double *__restrict__ Wm, const double *__restrict__ oglob,
                  const double *__restrict__ wkp, const int *__restrict__ gmap,
                  double *__restrict__ b, double *__restrict__ post, double *__restrict__ sink,
-                 const int *__restrict__ anyflag, int epoch)
+                 const int *__restrict__ anyflag, int epoch, const double *__restrict__ dtile,
+                 const int *__restrict__ tshift)
 {
     extern __shared__ double lds[];
     if (anyflag[0] == epoch) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
@@ -503,6 +588,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     // or the distance to the lane's sink slot, and the row stride {G, N} or 0 for the sink
     long long *offl = (long long *)(wkl + (size_t)TC * 16); // [TC][16][2]
     unsigned *strl = (unsigned *)(offl + (size_t)TC * 32);  // [TC][16][2]
+    // tiles that hold a variance-floored component take that component's mean as their offset:
+    // dl = offset - oglob (subtracted from the A fragments of that tile), tsl = "shifted"
+    double *dl = (double *)(strl + (size_t)TC * 32);        // [TC][DP]
+    int *tsl = (int *)(dl + (size_t)TC * DP);               // [TC]
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index, in a scalar register
     const int c0 = blockIdx.y * TC;
@@ -521,6 +610,8 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
         strl[2 * k + 1] = hold ? (unsigned)N : 0u;
     }
     for (int k = tid; k < DP; k += EMS_WAVES * WAVE) ol[k] = k < D ? oglob[k] : 0.0;
+    for (int k = tid; k < tc * DP; k += EMS_WAVES * WAVE) dl[k] = dtile[(size_t)c0 * DP + k];
+    for (int k = tid; k < tc; k += EMS_WAVES * WAVE) tsl[k] = tshift[c0 + k];
     __syncthreads();
     double *xw = xl + w * 16 * XS;
     const long long ntf = (F + 15) / 16;
@@ -592,7 +683,16 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
             for (int tt = 0; tt < TPS; tt++) {
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
                 const double *Wt = Wl + (size_t)(ct + tt) * KS * 64 + l;
-                if (AREG) {
+                if (__builtin_amdgcn_readfirstlane(tsl[ct + tt]) != 0) {
+                    // this tile's own offset: x'' = x' - (offset - oglob), from the slab
+                    const double *dq = dl + (ct + tt) * DP + kq;
+#pragma unroll 5
+                    for (int s = 0; s < Q; s++) {
+                        const double x1 = xr[4 * s] - dq[4 * s];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, Wt[s * 64], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1 * x1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                    }
+                } else if (AREG) {
 #pragma unroll
                     for (int s = 0; s < Q; s++) {
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[AREG ? s : 0], Wt[s * 64], acc, 0, 0, 0);
