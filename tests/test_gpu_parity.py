@@ -446,6 +446,36 @@ def test_ten_em_iterations_track_the_oracle(G, ctx):
         o.close()
 
 
+def test_em_from_the_references_initial_model_tracks_the_oracle(G, ctx):
+    """EM from creating_initial_model's result (TF:732-1317): within a few iterations some
+    components collapse onto single frames (variances at the 1e-5 floor, conditioning ~1e7 around
+    the data's centre), which is where the expanded Mahalanobis form needs its per-tile offsets
+    and, for two such components in one tile, the direct form.  Log-likelihood trace and final
+    model against the oracle over 8 iterations."""
+    N, M, D = 10, 8, 39
+    mean, std = G.synth_truth(N, M, D)
+    lens = np.full(48, 90, dtype=np.int32)
+    X = G.synth_utterances(mean, std, lens)
+    hm = G.synth_start_model(mean, std, 0.05)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    hm0 = model.init_from(corpus)
+    ref_hm, it, _, trace = O.train(hm0, X, lens, max_iter=8, fixed_iter=True)
+    stats = ctx.stats(N, M, D)
+    got = []
+    for _ in range(8):
+        ctx.estep(model, corpus, stats)
+        got.append(stats.download()[-2])
+        ctx.mstep(model, stats)
+    iv = np.asarray(model.get().arrays()[3]).reshape(N * M, D)
+    floored = int((iv > 9.0e4).all(axis=1).sum())
+    assert floored >= 1, "the case is meant to contain collapsed components"
+    assert_close(got, trace, rtol=1e-8, what="loglik trace")
+    for name, a, b in zip(("A", "c", "mean", "inv_var", "det"), model.get().arrays(), ref_hm.arrays()):
+        assert_close(a, b, rtol=1e-6, what="model." + name)
+    for o in (model, corpus, stats):
+        o.close()
+
+
 def test_delta_option_widens_the_transition_band(G, ctx):
     hm, X, lens = synth_case(G, 6, 2, 7, [50, 60], dense_A=True)
     model, corpus = ctx.model(hm), ctx.corpus(X, lens)
