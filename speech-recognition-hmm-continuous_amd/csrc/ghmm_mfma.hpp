@@ -11,10 +11,11 @@
 // instruction) and operands straight from LDS.
 //
 // Cancellation: the expanded form loses eps * sum_d inv_d mu'_d^2 absolutely, so
-// (1) frames and means are taken relative to one offset near the data's centre (oglob) and
-// (2) a model that still holds an ill-conditioned Gaussian (cond > COND_MAX, e.g. the
-// variance-floored "needle" components of SURVEY.md §7) has the affected tiles evaluated in
-// the reference's direct form (x-mu)*inv*(x-mu) by k_emission_mfma.
+// (1) frames and means are taken relative to an offset near the data's centre (oglob),
+// (2) a tile of 16 Gaussians that holds a variance-floored "needle" component (SURVEY.md §7;
+// cond ~ 1e7 around the centre) takes that component's mean as ITS offset (dtile / tshift) and
+// (3) a tile that is still ill-conditioned then (cond > COND_MAX: two needles in one tile) is
+// evaluated in the reference's direct form (x-mu)*inv*(x-mu) by k_emission_mfma.
 //
 // Fragment maps (cdna_hip_programming.md §3): lane l, A[i = l&15][k = l>>4],
 // B[k = l>>4][j = l&15], C/D reg r -> row (l>>4) + 4r, col l&15.
