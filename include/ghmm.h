@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GHMM_VERSION 100
+#define GHMM_VERSION 200
 
 enum {
     GHMM_OK = 0,
@@ -198,6 +198,9 @@ enum {
     GHMM_BUF_LOGNORM = 7 /* log of the per-frame normaliser [F] (GHMM_OPT_ROBUST) */
 };
 int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n_doubles);
+/* the same for doubles [first, first + n_doubles) of the buffer (e.g. a block of frames of a
+ * b[F][N] too large for host memory: BASELINE's 2 000-state x 1 M-frame emission is 16 GB) */
+int ghmm_fetch_range(ghmm_ctx *ctx, int which, size_t first, double *host, size_t n_doubles);
 
 /* -------------------------------------------------- the path, batched/fused */
 
@@ -208,7 +211,9 @@ int ghmm_estep(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *stats);
 /* M-step from (possibly all-reduced) statistics, on the device, in place:
  * updating_transition_probab TF:1862-1889, updating_mix_param TF:1911-1955 with
  * changing_zero_coef TF:1338-1359, calc_det TF:1976 + inv_matrix TF:2012 as
- * called at TF:343-346.  Asynchronous. */
+ * called at TF:343-346.  num_a is read inside the band i <= j <= i + GHMM_OPT_DELTA only —
+ * the only entries calc_transition_probab ever accumulates (TF:1601); a_ij outside it
+ * becomes 0 / den_a = 0 as in the reference.  Asynchronous. */
 int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *stats);
 /* Forward-algorithm score per utterance (RF:354-366): emission without
  * posteriors + alpha + log P.  Synchronises, writes loglik[U] on the host. */
@@ -222,9 +227,41 @@ int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_models, ghm
 /* Max-plus lattice with the reference's one-hot start (RF:249-251) and
  * final-state termination (TF:1487, TF:1549); ties take the lowest predecessor.
  * ABSENT from the reference: defined by oracle/.
- * path_host[F] = state per frame, score_host[U] = best log score. */
+ * path_host[F] = state per frame, score_host[U] = best log score.  (The device keeps
+ * one byte per frame; it is widened to int32 on the way into path_host.) */
 int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_t *path_host,
                  double *score_host);
+
+/* -------------------------------------- several GPUs: the one collective */
+
+/* Utterances shard data-parallel over ranks (one rank = one process or host thread with
+ * its own ghmm_ctx on its own GPU); the accumulators are plain sums over utterances
+ * (TF:1614, 1618, 1660, 1716-1722, 318-320), so the ONLY exchange per EM iteration is one
+ * sum of the flat statistics vector over ranks: ncclAllReduce(ncclDouble, ncclSum) of RCCL,
+ * in place, on the context's stream.  Every rank then applies the same
+ * ghmm_mstep redundantly (identical inputs, identical models, no broadcast).  RCCL
+ * (librccl.so.1) is loaded on the first ghmm_comm_* call; a process that never makes one
+ * does not touch it. */
+typedef struct ghmm_comm ghmm_comm;
+#define GHMM_COMM_ID_BYTES 128
+/* rank 0: a fresh rendezvous id (ncclGetUniqueId) to hand to every rank out of band */
+int ghmm_comm_unique_id(void *id_bytes);
+/* collective over all `world` ranks (ncclCommInitRank) */
+int ghmm_comm_create(ghmm_ctx *ctx, const void *id_bytes, int rank, int world, ghmm_comm **out);
+/* the same with the id passed through a file: rank 0 creates the id and writes `path`
+ * (atomically, via rename), the other ranks wait up to timeout_s for it to appear; rank 0
+ * removes the file once every rank has joined.  `path` must be unique per job. */
+int ghmm_comm_create_file(ghmm_ctx *ctx, const char *path, int rank, int world, double timeout_s,
+                          ghmm_comm **out);
+void ghmm_comm_destroy(ghmm_comm *comm);
+int ghmm_comm_rank(const ghmm_comm *comm);
+int ghmm_comm_size(const ghmm_comm *comm);
+/* stats <- sum over ranks of stats, in place, asynchronous on the context's stream */
+int ghmm_stats_allreduce(ghmm_ctx *ctx, ghmm_stats *stats, ghmm_comm *comm);
+/* ghmm_model_init over a corpus sharded across ranks: the k-means sums of every pass are
+ * all-reduced, every rank does the same cell bookkeeping and ends with the same model.
+ * comm == NULL: this rank's corpus alone (= ghmm_model_init). */
+int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_comm *comm);
 
 /* ------------------------------------------------- host side: file formats */
 
@@ -234,7 +271,16 @@ int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_t *path_hos
  * *X is malloc'ed; the caller frees it with ghmm_free(). */
 int ghmm_perfil_read(const char *path, int *D, int *T, double **X);
 int ghmm_perfil_write(const char *path, int D, int T, const double *X);
+/* coefficient count and frame count from the header and the file size, nothing else read */
+int ghmm_perfil_stat(const char *path, int *D, int *T);
 void ghmm_free(void *p);
+
+/* Length-balanced shard of `rank` among `world` (sort by length, deal in
+ * turn): index[0 .. *n_out) = this rank's utterances in ascending index order (index has
+ * room for (n_utt + world - 1) / world entries).  Frames per rank differ by at most the
+ * longest utterance. */
+int ghmm_shard_balanced(const int32_t *len, int n_utt, int rank, int world, int32_t *index,
+                        int *n_out);
 
 /* .hmm model file (writer TF:2043-2146, readers TF:604-711, RF:595-715), one
  * stream.  The reader accepts both a 4-byte and an 8-byte length prefix (the

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "ghmm_kernels.hpp"
@@ -77,11 +78,19 @@ struct ghmm_ctx {
     int slots = 0;             // partial-sum slots filled by the last backward / combine pass
     double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr;
     unsigned char *psi = nullptr;
-    int *path = nullptr;
+    unsigned char *path = nullptr; // Viterbi state per frame (N <= 255): one byte on the device
     // shape of what the workspace currently holds (for ghmm_fetch)
     long long F = 0;
     int U = 0, N = 0, G = 0;
     bool b_is_log = false;
+    // what the emission densities in the workspace belong to (ghmm_forward / ghmm_backward /
+    // ghmm_accumulate check it): model, its preparation count, corpus
+    const ghmm_model *em_m = nullptr;
+    const ghmm_corpus *em_c = nullptr;
+    int em_epoch = -1;
+    // kernels whose dynamic-LDS limit has been raised on THIS context's device (the attribute
+    // is per device and per function; nothing process-wide, nothing shared between threads)
+    std::vector<const void *> lds_fns;
     ktimer kt[GHMM_K_COUNT];
 };
 
@@ -110,6 +119,7 @@ struct ghmm_corpus {
     const double *X = nullptr;
     bool own = false;
     long long *off = nullptr; // device, U+1
+    int *order = nullptr;     // device, U: utterance indices by decreasing length (stable)
     std::vector<int32_t> len;
     long long F = 0;
     int U = 0, D = 0, Tmax = 0;
@@ -182,10 +192,27 @@ struct kscope { // brackets one kernel launch with HIP events when timing is on
 // (measured 1.4 GB/s on 12 MB of Viterbi paths); here the DMA goes into two pinned 16 MB
 // buffers in turn while the host copies the previous one out.  Synchronises the stream.
 constexpr size_t PIN_CHUNK = 16u << 20;
-static int d2h_pageable(ghmm_ctx *ctx, void *dst, const void *src, size_t bytes)
+// copy-out of one landed chunk: plain bytes, or bytes widened to int32 (Viterbi paths travel
+// as one byte per frame and are widened into the caller's int32 array)
+static inline void chunk_out(void *dst, size_t dst_off, const void *pin, size_t n, bool widen)
 {
-    if (bytes < (1u << 20)) {
+    if (!widen) {
+        memcpy((char *)dst + dst_off, pin, n);
+        return;
+    }
+    int32_t *o = (int32_t *)dst + dst_off;
+    const unsigned char *in = (const unsigned char *)pin;
+    for (size_t k = 0; k < n; k++) o[k] = in[k];
+}
+
+static int d2h_pageable(ghmm_ctx *ctx, void *dst, const void *src, size_t bytes, bool widen = false)
+{
+    if (bytes < (1u << 20) && !widen) {
         if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return GHMM_OK;
+    }
+    if (bytes == 0) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return GHMM_OK;
     }
@@ -196,14 +223,16 @@ static int d2h_pageable(ghmm_ctx *ctx, void *dst, const void *src, size_t bytes)
         }
     size_t off = 0, prev_off = 0, prev_n = 0;
     int k = 0;
+    // (widening: 4 MB pieces, so that the host loop over one piece runs under the next DMA)
+    const size_t piece = widen ? (PIN_CHUNK / 4 < bytes ? PIN_CHUNK / 4 : bytes) : PIN_CHUNK;
     while (off < bytes) {
-        const size_t n = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+        const size_t n = bytes - off < piece ? bytes - off : piece;
         const int cur = k & 1;
         HIP_TRY(hipMemcpyAsync(ctx->pin[cur], (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipEventRecord(ctx->pin_ev[cur], ctx->stream));
         if (prev_n) {
             HIP_TRY(hipEventSynchronize(ctx->pin_ev[cur ^ 1]));
-            memcpy((char *)dst + prev_off, ctx->pin[cur ^ 1], prev_n);
+            chunk_out(dst, prev_off, ctx->pin[cur ^ 1], prev_n, widen);
         }
         prev_off = off;
         prev_n = n;
@@ -211,8 +240,20 @@ static int d2h_pageable(ghmm_ctx *ctx, void *dst, const void *src, size_t bytes)
         k++;
     }
     HIP_TRY(hipEventSynchronize(ctx->pin_ev[(k - 1) & 1]));
-    memcpy((char *)dst + prev_off, ctx->pin[(k - 1) & 1], prev_n);
+    chunk_out(dst, prev_off, ctx->pin[(k - 1) & 1], prev_n, widen);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+// Raise a kernel's dynamic shared-memory limit to 150 KB on the context's device, once per
+// (context, kernel).  Per-context state: two contexts on two devices each set it for their
+// own device, two host threads never share a flag.
+static int lds_attr(ghmm_ctx *ctx, const void *fn)
+{
+    for (const void *p : ctx->lds_fns)
+        if (p == fn) return GHMM_OK;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ctx->lds_fns.push_back(fn);
     return GHMM_OK;
 }
 
@@ -406,7 +447,6 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
     if ((rc = launch_ok("k_prepare")) || !m->mfma_ok) return rc;
     {
         kscope ks(ctx, GHMM_K_PREPARE);
-        m->epoch++;
         hipLaunchKernelGGL(k_prepare_offsets, dim3((unsigned)(m->NT + m->D)), dim3(64), 0, ctx->stream,
                            m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->offs, m->oglob);
         hipLaunchKernelGGL(k_prepare_tiles, dim3((unsigned)m->NT), dim3(64), 0, ctx->stream, m->N, m->M,
@@ -470,12 +510,19 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
                 ghmm_model_destroy(ctx, m);
                 return rc;
             }
-            (void)hipMemset(m->dtile, 0, (size_t)m->NT * m->DP * 8);
-            (void)hipMemset(m->otile, 0, (size_t)m->NT * m->DP * 8);
-            (void)hipMemset(m->tshift, 0, (size_t)m->NT * sizeof(int));
-            (void)hipMemset(m->condt, 0, (size_t)m->NT * 16 * 8);
-            (void)hipMemset(m->sflag, 0, sizeof(int));
-            (void)hipMemset(m->tnext, 0, (size_t)m->NT * sizeof(int));
+            // on the context's stream, like every consumer of these buffers
+            hipError_t e = hipMemsetAsync(m->dtile, 0, (size_t)m->NT * m->DP * 8, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(m->otile, 0, (size_t)m->NT * m->DP * 8, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(m->tshift, 0, (size_t)m->NT * sizeof(int), ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(m->condt, 0, (size_t)m->NT * 16 * 8, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(m->sflag, 0, sizeof(int), ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(m->anyflag, 0, sizeof(int), ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(m->tnext, 0, (size_t)m->NT * sizeof(int), ctx->stream);
+            if (e != hipSuccess) {
+                ghmm_set_error("ghmm_model_create: hipMemsetAsync failed: %s", hipGetErrorString(e));
+                ghmm_model_destroy(ctx, m);
+                return GHMM_ERR_HIP;
+            }
             // statistics kernel: NE feature tiles of 16 over [x', 1, x'^2]; CT Gaussian tiles
             // per wave so that CT*NE accumulator tiles (8 VGPRs each) stay near 200 VGPRs
             m->NE = (2 * m->DP + 15) / 16;
@@ -491,6 +538,7 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
 {
     if (!m) return;
     if (ctx && ctx->last_m == m) ctx->last_m = nullptr;
+    if (ctx && ctx->em_m == m) ctx->em_m = nullptr;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
@@ -522,6 +570,7 @@ extern "C" int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, con
     HIP_TRY(hipMemcpyAsync(m->det, det, G * 8, hipMemcpyHostToDevice, ctx->stream));
     // pageable host memory: the copies above have consumed the buffers on return
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    m->epoch++; // a new set of parameters
     return model_prepare(ctx, m, true);
 }
 
@@ -575,28 +624,41 @@ static int corpus_make(ghmm_ctx *ctx, const double *X_host, const double *X_dev,
         if (len[u] > c->Tmax) c->Tmax = len[u];
     }
     c->F = off[n_utt];
-    if ((rc = dev_alloc(&c->off, off.size()))) {
+    // length order for the scans: a wave holds 4 utterances and runs as long as its longest,
+    // and the longest chains should start first (stable: equal lengths keep corpus order)
+    std::vector<int> ord((size_t)n_utt);
+    for (int u = 0; u < n_utt; u++) ord[u] = u;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len[a] > len[b]; });
+    if ((rc = dev_alloc(&c->off, off.size())) || (rc = dev_alloc(&c->order, ord.size()))) {
+        if (c->off) (void)hipFree(c->off);
         delete c;
         return rc;
     }
-    hipError_t e = hipMemcpy(c->off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(c->off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess && n_utt)
+        e = hipMemcpyAsync(c->order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && X_host) {
         double *xd = nullptr;
         if ((rc = dev_alloc(&xd, (size_t)c->F * D))) {
             (void)hipFree(c->off);
+            (void)hipFree(c->order);
             delete c;
             return rc;
         }
         c->X = xd;
         c->own = true;
-        if (c->F) e = hipMemcpy(xd, X_host, (size_t)c->F * D * 8, hipMemcpyHostToDevice);
+        if (c->F) e = hipMemcpyAsync(xd, X_host, (size_t)c->F * D * 8, hipMemcpyHostToDevice, ctx->stream);
     } else {
         c->X = X_dev;
     }
+    // pageable host memory (and the local `off`): consumed when the stream has drained
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ghmm_set_error("corpus upload failed: %s", hipGetErrorString(e));
         if (c->own) (void)hipFree((void *)c->X);
         (void)hipFree(c->off);
+        (void)hipFree(c->order);
         delete c;
         return GHMM_ERR_HIP;
     }
@@ -623,12 +685,14 @@ extern "C" void ghmm_corpus_destroy(ghmm_ctx *ctx, ghmm_corpus *c)
 {
     if (!c) return;
     if (ctx && ctx->last_c == c) ctx->last_c = nullptr;
+    if (ctx && ctx->em_c == c) ctx->em_c = nullptr;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
     if (c->own && c->X) (void)hipFree((void *)c->X);
     if (c->off) (void)hipFree(c->off);
+    if (c->order) (void)hipFree(c->order);
     delete c;
 }
 
@@ -772,6 +836,13 @@ static int ws_fb(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
 
 static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, bool want_post)
 {
+    // the workspace is rewritten: alpha^ / W / 1/s of an earlier E-step no longer go with its b
+    // (ghmm_fetch(GHMM_BUF_BETA) refuses instead of rebuilding beta^ from mixed buffers)
+    ctx->last_m = nullptr;
+    ctx->last_c = nullptr;
+    ctx->em_m = m;
+    ctx->em_c = c;
+    ctx->em_epoch = m->epoch;
     if (c->F == 0) return GHMM_OK;
     const long long blocks = (c->F + WAVE - 1) / WAVE;
     const size_t lds = (size_t)WAVE * (m->D | 1) * sizeof(double);
@@ -785,7 +856,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
     if (mode == 2 && sched_ok) {
         // log b for the Viterbi lattice on the matrix-core kernel; with an ill-conditioned
         // Gaussian in the model it returns at once and the vector-ALU kernel below runs
-        static bool attr_set[8] = {false};
+        int rc;
         const long long ntf = (c->F + 15) / 16;
         const int chunks = (m->NT + m->TC - 1) / m->TC;
         const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
@@ -797,11 +868,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         kscope ks(ctx, GHMM_K_EMISSION);
 #define GHMM_EML(MP, IDX)                                                                         \
     do {                                                                                          \
-        if (!attr_set[IDX]) {                                                                     \
-            (void)hipFuncSetAttribute((const void *)k_emission_sched<20, MP, 2>,                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  \
-            attr_set[IDX] = true;                                                                 \
-        }                                                                                         \
+        if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, 2>))) return rc;          \
         hipLaunchKernelGGL((k_emission_sched<20, MP, 2>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,  \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->logwkp, m->gmap, ctx->b,       \
@@ -819,12 +886,8 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         }
     }
     if (mode == 0 && m->mfma_ok && ctx->kernels != 1) {
-        static bool lds_attr_set = false;
-        if (!lds_attr_set) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_emission_mfma,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            lds_attr_set = true;
-        }
+        int rc;
+        if ((rc = lds_attr(ctx, (const void *)k_emission_mfma))) return rc;
         const long long ntf = (c->F + 15) / 16;
         const int chunks = (m->NT + m->TC - 1) / m->TC;
         long long gx = (ntf + EM_WAVES - 1) / EM_WAVES;
@@ -845,12 +908,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
             if (sched) {
 #define GHMM_EMS(MP, PO)                                                                          \
     do {                                                                                          \
-        static bool attr_##MP##_##PO = false;                                                     \
-        if (!attr_##MP##_##PO) {                                                                  \
-            (void)hipFuncSetAttribute((const void *)k_emission_sched<20, MP, PO>,                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  \
-            attr_##MP##_##PO = true;                                                              \
-        }                                                                                         \
+        if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, PO>))) return rc;         \
         hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,   \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap, ctx->b, post,     \
@@ -934,6 +992,8 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_b
     const int gpw = WAVE / L;
     const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
     const double *ln = ctx->robust ? ctx->lognorm : nullptr;
+    ctx->last_m = nullptr; // alpha^ is rewritten: run_backward re-arms these
+    ctx->last_c = nullptr;
     ctx->own_bwd_done = false;
     ctx->beta_valid = false;
     ctx->loglik_pieces = use_pair(ctx) && with_backward; // k_combine will take the logs
@@ -945,18 +1005,18 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_b
             if (L == 16)
                 hipLaunchKernelGGL(k_scan_pair<16>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                    only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
-                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
             else
                 hipLaunchKernelGGL(k_scan_pair<64>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                    only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
-                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
             ctx->own_bwd_done = with_backward;
         } else if (L == 16)
             hipLaunchKernelGGL(k_forward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink);
+                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink, c->order);
         else
             hipLaunchKernelGGL(k_forward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink);
+                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink, c->order);
     }
     return launch_ok("k_forward");
 }
@@ -979,11 +1039,11 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
                 if (L == 16)
                     hipLaunchKernelGGL(k_scan_pair<16>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream, m->N,
                                        c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
                 else
                     hipLaunchKernelGGL(k_scan_pair<64>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream, m->N,
                                        c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink);
+                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
                 ctx->own_bwd_done = true;
             }
             const unsigned cb = (unsigned)(((long long)c->U * CB_CH + gpw - 1) / gpw);
@@ -992,7 +1052,7 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
                        (int)ctx->delta, m->A, c->off, ctx->alpha, ctx->scale, ctx->wrow, ctx->sb, \
                        ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, \
                        ctx->robust ? ctx->lognorm : (const double *)nullptr,                     \
-                       ctx->loglik_pieces ? ctx->lpart : (double *)nullptr, ctx->logk)
+                       ctx->loglik_pieces ? ctx->lpart : (double *)nullptr, ctx->logk, c->order)
             // the M-step keeps a band-diagonal A band-diagonal as long as it re-estimates
             // no transition beyond i -> i + 1
             const bool band2 = m->banded && ctx->delta <= 1;
@@ -1014,11 +1074,11 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
             if (L == 16)
                 hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                    (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
+                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order);
             else
                 hipLaunchKernelGGL(k_backward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                    (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink);
+                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order);
             ctx->beta_valid = true;
             ctx->slots = c->U;
         }
@@ -1028,7 +1088,8 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
 
 static int need_emission(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
 {
-    if (!ctx->b || ctx->F != c->F || ctx->U != c->U || ctx->N != m->N || ctx->b_is_log) {
+    if (!ctx->b || ctx->F != c->F || ctx->U != c->U || ctx->N != m->N || ctx->b_is_log ||
+        ctx->em_m != m || ctx->em_c != c || ctx->em_epoch != m->epoch) {
         ghmm_set_error("call ghmm_emission on this model and corpus first");
         return GHMM_ERR_ARG;
     }
@@ -1067,12 +1128,8 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
         const int GWmax = CT * 16 < G ? CT * 16 : G;
         size_t stage = (size_t)MSM_WAVES * (16 * (NE * 16 + GWmax + m->N) + m->DP) * sizeof(double);
         size_t lds = stage > fold ? stage : fold;
-        static bool attr = false;
-        if (!attr) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_mixstats_mfma<CT, NE, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr = true;
-        }
+        int rc;
+        if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true>))) return rc;
         if (lds <= 150 * 1024) {
             // one launch per chunk so that gmin / GW are plain arguments (chunks == 1 at 10x8)
             for (int ch = 0; ch < chunks; ch++) {
@@ -1086,12 +1143,8 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
             return GHMM_OK;
         }
     }
-    static bool attr_ns = false;
-    if (!attr_ns) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_mixstats_mfma<CT, NE, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_ns = true;
-    }
+    int rc;
+    if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, false>))) return rc;
     hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, false>), dim3((unsigned)P, (unsigned)chunks),
                        dim3(MSM_WAVES * WAVE), fold, ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT,
                        c->F, 0, 0, c->X, ctx->gamma, ctx->post, m->gmap, m->oglob, ctx->part_m);
@@ -1219,11 +1272,11 @@ extern "C" int ghmm_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghm
     return run_accumulate(ctx, m, c, s);
 }
 
-extern "C" int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n)
+static int fetch_impl(ghmm_ctx *ctx, int which, bool whole, size_t first, double *host, size_t n)
 {
     int rc = use(ctx);
     if (rc) return rc;
-    ARG_CHECK(host, "null destination");
+    ARG_CHECK(host || n == 0, "null destination");
     const double *src = nullptr;
     size_t have = 0;
     size_t F = (size_t)ctx->F, N = (size_t)ctx->N, G = (size_t)ctx->G, U = (size_t)ctx->U;
@@ -1259,11 +1312,22 @@ extern "C" int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n)
         ghmm_set_error("unknown buffer %d", which);
         return GHMM_ERR_ARG;
     }
-    if (!src || n != have) {
-        ghmm_set_error("buffer %d holds %zu doubles, %zu requested", which, src ? have : 0, n);
+    if (!src || (whole ? n != have : (first > have || n > have - first))) {
+        ghmm_set_error("buffer %d holds %zu doubles, [%zu, %zu) requested", which, src ? have : 0, first,
+                       first + n);
         return GHMM_ERR_ARG;
     }
-    return d2h_pageable(ctx, host, src, n * 8);
+    return d2h_pageable(ctx, host, src + first, n * 8);
+}
+
+extern "C" int ghmm_fetch(ghmm_ctx *ctx, int which, double *host, size_t n)
+{
+    return fetch_impl(ctx, which, true, 0, host, n);
+}
+
+extern "C" int ghmm_fetch_range(ghmm_ctx *ctx, int which, size_t first, double *host, size_t n)
+{
+    return fetch_impl(ctx, which, false, first, host, n);
 }
 
 // -------------------------------------------------------------------- fused
@@ -1286,6 +1350,10 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
     if (rc) return rc;
     ARG_CHECK(m, "null model");
     if ((rc = check_stats(m, s))) return rc;
+    m->epoch++; // a new set of parameters (and a new preparation of the matrix-core form)
+    // transitions are re-estimated inside the band i <= j <= i + delta only (TF:1601): a
+    // band-diagonal A stays band-diagonal exactly when that band is i, i + 1
+    m->banded = m->banded && ctx->delta <= 1;
     {
         kscope ks(ctx, GHMM_K_MSTEP);
         size_t md = (size_t)m->M * m->D;
@@ -1293,18 +1361,18 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
         int lds_doubles = (md + m->M) * 8 <= 56 * 1024 ? (int)(md + m->M) : 0;
         if (m->mfma_ok) {
             // M-step and matrix-core preparation of the new model in one launch
-            m->epoch++;
             hipLaunchKernelGGL(k_mstep_mfma, dim3((unsigned)m->N), dim3(MSF_THREADS),
                                ((size_t)lds_doubles + m->DP + MSF_THREADS) * 8, ctx->stream, m->N, m->M, m->D, s->v,
                                pow(2.0 * M_PI, m->D / 2.0), m->A, m->c, m->mean, m->inv_var, m->det, m->wk,
                                m->logwk, m->logA, lds_doubles, m->Mp, m->NT, m->DP, m->oglob, m->Wm, m->wkp,
                                m->logwkp, m->gmap, m->condg, m->anyflag, m->epoch, m->otile, m->tnext,
-                               m->condt, m->dtile, m->tshift, m->sflag);
+                               m->condt, m->dtile, m->tshift, m->sflag, (int)ctx->delta);
             return launch_ok("k_mstep_mfma");
         }
         hipLaunchKernelGGL(k_mstep, dim3((unsigned)m->N), dim3(MS2_THREADS), (size_t)lds_doubles * 8,
                            ctx->stream, m->N, m->M, m->D, s->v, pow(2.0 * M_PI, m->D / 2.0), m->A, m->c,
-                           m->mean, m->inv_var, m->det, m->wk, m->logwk, m->logA, lds_doubles);
+                           m->mean, m->inv_var, m->det, m->wk, m->logwk, m->logA, lds_doubles,
+                           (int)ctx->delta);
     }
     if ((rc = launch_ok("k_mstep"))) return rc;
     return model_prepare(ctx, m, false);
@@ -1314,6 +1382,11 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
 // statistics through the vector-ALU statistics kernel: direct (x - mean)^2, no expanded
 // form), cell bookkeeping on the host exactly as the reference orders it.
 extern "C" int ghmm_model_init(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
+{
+    return ghmm_model_init_comm(ctx, m, c, nullptr);
+}
+
+extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_comm *comm)
 {
     int rc = use(ctx);
     if (rc || (rc = check_pair(m, c))) return rc;
@@ -1357,6 +1430,9 @@ extern "C" int ghmm_model_init(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
                                ctx->gamma, ctx->post);
         }
         if ((r = launch_ok("k_init_classify")) || (r = run_accumulate(ctx, m, c, st))) return r;
+        // a corpus sharded over ranks: the cell sums of all shards (every rank then does the
+        // same bookkeeping on the same numbers)
+        if (comm && (r = ghmm_stats_allreduce(ctx, st, comm))) return r;
         if ((r = ghmm_stats_download(ctx, st, sv.data()))) return r;
         for (int g = 0; g < G; g++) {
             double d = 0.0;
@@ -1472,10 +1548,10 @@ extern "C" int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_
     if (rc) return rc;
     ARG_CHECK(models && n_models > 0 && c, "null argument");
     ARG_CHECK(loglik_host || c->U == 0, "null destination");
+    for (int k = 0; k < n_models; k++) ARG_CHECK(models[k], "null model");
     const int M = models[0]->M, D = models[0]->D;
     int NS = 0, Nmax = 0;
     for (int k = 0; k < n_models; k++) {
-        ARG_CHECK(models[k], "null model");
         if (models[k]->M != M || models[k]->D != D) {
             ghmm_set_error("ghmm_score_batch: every model must have the same M and D");
             return GHMM_ERR_UNSUPPORTED;
@@ -1539,6 +1615,7 @@ extern "C" int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_
         cleanup();
         return GHMM_ERR_HIP;
     }
+    cat->epoch++;
     if ((rc = model_prepare(ctx, cat, true)) || (rc = ws_frames(ctx, cat, c, false)) ||
         (rc = run_emission(ctx, cat, c, ctx->robust ? 1 : 0, false))) {
         cleanup();
@@ -1558,11 +1635,11 @@ extern "C" int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_
         if (L == 16)
             hipLaunchKernelGGL(k_forward_multi<16>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
                                ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
-                               ctx->sink);
+                               ctx->sink, c->order);
         else
             hipLaunchKernelGGL(k_forward_multi<64>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
                                ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
-                               ctx->sink);
+                               ctx->sink, c->order);
     }
     rc = launch_ok("k_forward_multi");
     if (!rc) {
@@ -1598,16 +1675,193 @@ extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_
             kscope ks(ctx, GHMM_K_VITERBI);
             if (L == 16)
                 hipLaunchKernelGGL(k_viterbi<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
-                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik);
+                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, c->order);
             else
                 hipLaunchKernelGGL(k_viterbi<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
-                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik);
+                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, c->order);
         }
         if ((rc = launch_ok("k_viterbi"))) return rc;
         HIP_TRY(hipMemcpyAsync(score_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,
                                ctx->stream));
-        if (c->F && (rc = d2h_pageable(ctx, path_host, ctx->path, (size_t)c->F * sizeof(int)))) return rc;
+        if (c->F && (rc = d2h_pageable(ctx, path_host, ctx->path, (size_t)c->F, true))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+// ------------------------------------------------------------ collective (RCCL)
+// One sum of the statistics vector over ranks per EM iteration.  RCCL is
+// resolved at run time from librccl.so.1: a single-GPU process never loads it, and a process
+// that already holds an RCCL (e.g. torch's) shares that copy instead of mapping a second one.
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and enums; the five entry points come from dlsym
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <mutex>
+
+namespace {
+struct rccl_api {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    char why[256] = {0};
+};
+rccl_api g_rccl;          // written once under g_rccl_once, read-only afterwards
+std::once_flag g_rccl_once;
+
+const rccl_api *rccl()
+{
+    std::call_once(g_rccl_once, [] {
+        const char *env = getenv("GHMM_RCCL_LIB");
+        const char *names[] = {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (g_rccl.handle) break;
+            snprintf(g_rccl.why, sizeof g_rccl.why, "%s", dlerror());
+        }
+        if (!g_rccl.handle) return;
+        g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.handle, "ncclGetUniqueId");
+        g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.handle, "ncclCommInitRank");
+        g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.handle, "ncclCommDestroy");
+        g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(g_rccl.handle, "ncclAllReduce");
+        g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.handle, "ncclGetErrorString");
+        if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce ||
+            !g_rccl.GetErrorString) {
+            snprintf(g_rccl.why, sizeof g_rccl.why, "librccl lacks an entry point");
+            g_rccl.handle = nullptr;
+        }
+    });
+    return g_rccl.handle ? &g_rccl : nullptr;
+}
+} // namespace
+
+struct ghmm_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+#define RCCL_TRY(api, expr)                                                                 \
+    do {                                                                                    \
+        ncclResult_t r_ = (expr);                                                           \
+        if (r_ != ncclSuccess) {                                                            \
+            ghmm_set_error("%s failed: %s", #expr, (api)->GetErrorString(r_));              \
+            return GHMM_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+static const rccl_api *rccl_or_error()
+{
+    const rccl_api *api = rccl();
+    if (!api) ghmm_set_error("RCCL is not available: %s", g_rccl.why);
+    return api;
+}
+
+extern "C" int ghmm_comm_unique_id(void *id_bytes)
+{
+    ARG_CHECK(id_bytes, "null id");
+    static_assert(sizeof(ncclUniqueId) == GHMM_COMM_ID_BYTES, "id size");
+    const rccl_api *api = rccl_or_error();
+    if (!api) return GHMM_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    RCCL_TRY(api, api->GetUniqueId(&id));
+    memcpy(id_bytes, &id, sizeof id);
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_comm_create(ghmm_ctx *ctx, const void *id_bytes, int rank, int world, ghmm_comm **out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(out && id_bytes && world > 0 && rank >= 0 && rank < world, "bad arguments");
+    *out = nullptr;
+    const rccl_api *api = rccl_or_error();
+    if (!api) return GHMM_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    ghmm_comm *cm = new (std::nothrow) ghmm_comm();
+    if (!cm) return GHMM_ERR_ALLOC;
+    cm->rank = rank;
+    cm->world = world;
+    cm->device = ctx->device;
+    ncclResult_t r = api->CommInitRank(&cm->comm, world, id, rank); // on the context's device (use())
+    if (r != ncclSuccess) {
+        ghmm_set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device,
+                       api->GetErrorString(r));
+        delete cm;
+        return GHMM_ERR_HIP;
+    }
+    *out = cm;
+    return GHMM_OK;
+}
+
+extern "C" int ghmm_comm_create_file(ghmm_ctx *ctx, const char *path, int rank, int world, double timeout_s,
+                                     ghmm_comm **out)
+{
+    ARG_CHECK(path && *path && out, "bad arguments");
+    unsigned char id[GHMM_COMM_ID_BYTES];
+    int rc;
+    if (rank == 0) {
+        if ((rc = ghmm_comm_unique_id(id))) return rc;
+        std::vector<char> tmp(strlen(path) + 32);
+        snprintf(tmp.data(), tmp.size(), "%s.tmp.%ld", path, (long)getpid());
+        FILE *f = fopen(tmp.data(), "wb");
+        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp.data(), path) != 0) {
+            ghmm_set_error("cannot publish the communicator id in %s", path);
+            return GHMM_ERR_IO;
+        }
+    } else {
+        const double step = 0.01;
+        double waited = 0.0;
+        for (;;) {
+            struct stat st;
+            FILE *f = (stat(path, &st) == 0 && st.st_size == (off_t)sizeof id) ? fopen(path, "rb") : nullptr;
+            if (f) {
+                const size_t n = fread(id, 1, sizeof id, f);
+                fclose(f);
+                if (n == sizeof id) break;
+            }
+            if (waited >= timeout_s) {
+                ghmm_set_error("rank %d: no communicator id in %s after %.0f s", rank, path, timeout_s);
+                return GHMM_ERR_IO;
+            }
+            usleep((useconds_t)(step * 1e6));
+            waited += step;
+        }
+    }
+    rc = ghmm_comm_create(ctx, id, rank, world, out);
+    if (rank == 0) (void)unlink(path); // every rank has joined (or the job has failed)
+    return rc;
+}
+
+extern "C" void ghmm_comm_destroy(ghmm_comm *cm)
+{
+    if (!cm) return;
+    const rccl_api *api = rccl();
+    if (api && cm->comm) {
+        (void)hipSetDevice(cm->device);
+        (void)api->CommDestroy(cm->comm);
+    }
+    delete cm;
+}
+
+extern "C" int ghmm_comm_rank(const ghmm_comm *cm) { return cm ? cm->rank : -1; }
+extern "C" int ghmm_comm_size(const ghmm_comm *cm) { return cm ? cm->world : -1; }
+
+extern "C" int ghmm_stats_allreduce(ghmm_ctx *ctx, ghmm_stats *s, ghmm_comm *cm)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(s && cm && cm->comm, "null argument");
+    ARG_CHECK(cm->device == ctx->device, "communicator and context are on different devices");
+    const rccl_api *api = rccl_or_error();
+    if (!api) return GHMM_ERR_UNSUPPORTED;
+    // in place, on the stream that carries the E-step before it and the M-step after it
+    RCCL_TRY(api, api->AllReduce(s->v, s->v, s->n, ncclDouble, ncclSum, cm->comm, ctx->stream));
     return GHMM_OK;
 }

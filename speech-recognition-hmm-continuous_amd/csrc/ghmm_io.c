@@ -97,6 +97,76 @@ int ghmm_perfil_read(const char *path, int *D, int *T, double **X)
     return GHMM_OK;
 }
 
+int ghmm_perfil_stat(const char *path, int *D, int *T)
+{
+    if (!path || !D || !T) return GHMM_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        ghmm_set_error("file %s not found", path);
+        return GHMM_ERR_IO;
+    }
+    int32_t d = 0;
+    long size = file_size(f);
+    int bad = size < 4 || fread(&d, sizeof d, 1, f) != 1 || d <= 0 || d > (1 << 20);
+    fclose(f);
+    if (bad) {
+        ghmm_set_error("%s: not a .perfil file", path);
+        return GHMM_ERR_FORMAT;
+    }
+    *D = d;
+    *T = (int)((size - 4) / (long)(sizeof(double) * (size_t)d));
+    return GHMM_OK;
+}
+
+/* Length-balanced utterance shards: utterances ordered by decreasing
+ * length (ties: lower index first), dealt to the ranks in turn; each rank's list is then
+ * put back in index order so that a rank reads its files in list order. */
+int ghmm_shard_balanced(const int32_t *len, int n_utt, int rank, int world, int32_t *index,
+                        int *n_out)
+{
+    if (n_utt < 0 || (!len && n_utt > 0) || world <= 0 || rank < 0 || rank >= world || !index || !n_out)
+        return GHMM_ERR_ARG;
+    int32_t *ord = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_utt > 0 ? n_utt : 1));
+    if (!ord) return GHMM_ERR_ALLOC;
+    /* stable counting order over the distinct lengths would need their range: a plain
+       merge sort on (-len, index) keeps it O(n log n) and stable */
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_utt > 0 ? n_utt : 1));
+    if (!tmp) {
+        free(ord);
+        return GHMM_ERR_ALLOC;
+    }
+    for (int i = 0; i < n_utt; i++) ord[i] = i;
+    for (int w = 1; w < n_utt; w *= 2) {
+        for (int lo = 0; lo < n_utt; lo += 2 * w) {
+            int mid = lo + w < n_utt ? lo + w : n_utt, hi = lo + 2 * w < n_utt ? lo + 2 * w : n_utt;
+            int a = lo, b = mid, k = lo;
+            while (a < mid && b < hi) tmp[k++] = len[ord[b]] > len[ord[a]] ? ord[b++] : ord[a++];
+            while (a < mid) tmp[k++] = ord[a++];
+            while (b < hi) tmp[k++] = ord[b++];
+        }
+        int32_t *sw = ord;
+        ord = tmp;
+        tmp = sw;
+    }
+    int n = 0;
+    for (int k = rank; k < n_utt; k += world) index[n++] = ord[k];
+    /* back into index order (insertion sort is quadratic: merge again) */
+    for (int w = 1; w < n; w *= 2) {
+        for (int lo = 0; lo < n; lo += 2 * w) {
+            int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int a = lo, b = mid, k = lo;
+            while (a < mid && b < hi) tmp[k++] = index[b] < index[a] ? index[b++] : index[a++];
+            while (a < mid) tmp[k++] = index[a++];
+            while (b < hi) tmp[k++] = index[b++];
+        }
+        memcpy(index, tmp, sizeof(int32_t) * (size_t)n);
+    }
+    *n_out = n;
+    free(ord);
+    free(tmp);
+    return GHMM_OK;
+}
+
 int ghmm_perfil_write(const char *path, int D, int T, const double *X)
 {
     if (!path || D <= 0 || T < 0 || (!X && T > 0)) return GHMM_ERR_ARG;

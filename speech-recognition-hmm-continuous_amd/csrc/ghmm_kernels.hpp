@@ -483,11 +483,12 @@ k_forward(int N, int U, const double *__restrict__ A, const double *__restrict__
           const long long *__restrict__ off, double *__restrict__ alpha,
           double *__restrict__ scale, double *__restrict__ sinv,
           const double *__restrict__ lognorm, double *__restrict__ loglik,
-          double *__restrict__ sink)
+          double *__restrict__ sink, const int *__restrict__ order)
 {
-    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    const int slot = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
-    if (u >= U) return;
+    if (slot >= U) return;
+    const int u = order[slot]; // neighbours in length order share a wave
     forward_utt<L>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink);
 }
 
@@ -505,12 +506,14 @@ __global__ void __launch_bounds__(WAVE)
 k_forward_multi(int U, int NS, long long F, const fwd_model *__restrict__ tab,
                 const double *__restrict__ b, const long long *__restrict__ off,
                 double *__restrict__ scale, double *__restrict__ sinv,
-                double *__restrict__ loglik, double *__restrict__ sink)
+                double *__restrict__ loglik, double *__restrict__ sink,
+                const int *__restrict__ order)
 {
-    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    const int slot = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
     const int k = blockIdx.y;
-    if (u >= U) return;
+    if (slot >= U) return;
+    const int u = order[slot];
     const fwd_model mk = tab[k];
     const int N = mk.N;
     const double *A = mk.A;
@@ -681,11 +684,12 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
            const double *__restrict__ scale, const double *__restrict__ sinv,
            double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ part_xi,
            double *__restrict__ part_dena, double *__restrict__ part_denc,
-           double *__restrict__ sink)
+           double *__restrict__ sink, const int *__restrict__ order)
 {
-    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    const int slot = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
-    if (u >= U) return;
+    if (slot >= U) return;
+    const int u = order[slot];
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     const bool act = i < N;
@@ -1015,7 +1019,7 @@ __device__ inline void mstep_state(int N, int M, int D, const double *__restrict
                                    double *__restrict__ A, double *__restrict__ c, double *__restrict__ mean,
                                    double *__restrict__ inv_var, double *__restrict__ det,
                                    double *__restrict__ wk, double *__restrict__ logwk,
-                                   double *__restrict__ logA, int lds_doubles, double *vs)
+                                   double *__restrict__ logA, int lds_doubles, double *vs, int delta)
 {
     const int G = N * M, i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const double *num_a = stats, *den_a = num_a + (size_t)N * N, *den_c = den_a + N;
@@ -1023,7 +1027,9 @@ __device__ inline void mstep_state(int N, int M, int D, const double *__restrict
     for (int j = tid; j < N; j += nt) {
         double v = A[i * N + j];
         if (den_a[i] != 0.0) {
-            v = num_a[i * N + j] / den_a[i];
+            // num_a is only ever accumulated for i <= j <= i + delta (TF:1601): outside that
+            // band the reference's quotient is 0 / den_a = 0, whatever the vector holds there
+            v = (j >= i && j <= i + delta) ? num_a[i * N + j] / den_a[i] : 0.0;
             A[i * N + j] = v;
         }
         logA[i * N + j] = v > 0.0 ? log(v) : -INFINITY;
@@ -1123,10 +1129,10 @@ __global__ void __launch_bounds__(MS2_THREADS)
 k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
         double *__restrict__ A, double *__restrict__ c, double *__restrict__ mean,
         double *__restrict__ inv_var, double *__restrict__ det, double *__restrict__ wk,
-        double *__restrict__ logwk, double *__restrict__ logA, int lds_doubles)
+        double *__restrict__ logwk, double *__restrict__ logA, int lds_doubles, int delta)
 {
     extern __shared__ double vs[];
-    mstep_state(N, M, D, stats, norm2pi, A, c, mean, inv_var, det, wk, logwk, logA, lds_doubles, vs);
+    mstep_state(N, M, D, stats, norm2pi, A, c, mean, inv_var, det, wk, logwk, logA, lds_doubles, vs, delta);
 }
 
 // --------------------------------------------------------------- init model
@@ -1188,11 +1194,13 @@ template <int L>
 __global__ void __launch_bounds__(WAVE)
 k_viterbi(int N, int U, const double *__restrict__ logA, const double *__restrict__ logb,
           const long long *__restrict__ off, unsigned char *__restrict__ psi,
-          int *__restrict__ path, double *__restrict__ score)
+          unsigned char *__restrict__ path, double *__restrict__ score,
+          const int *__restrict__ order)
 {
-    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    const int slot = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int j = threadIdx.x % L;
-    if (u >= U) return;
+    if (slot >= U) return;
+    const int u = order[slot];
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     if (T <= 0) {
@@ -1242,7 +1250,7 @@ k_viterbi(int N, int U, const double *__restrict__ logA, const double *__restric
         score[u] = sc;
         int s = N - 1;
         for (int t = T - 1; t >= 0; t--) {
-            path[f0 + t] = s;
+            path[f0 + t] = (unsigned char)s;
             s = ps[(size_t)t * N + s];
         }
     }

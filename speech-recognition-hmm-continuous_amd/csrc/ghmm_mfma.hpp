@@ -206,7 +206,7 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
              double *__restrict__ logwkp, int *__restrict__ gmap, double *__restrict__ condg,
              int *__restrict__ anyflag, int epoch, const double *__restrict__ otile,
              const int *__restrict__ tnext, double *__restrict__ condt, double *__restrict__ dtile,
-             int *__restrict__ tshift, int *__restrict__ sflag)
+             int *__restrict__ tshift, int *__restrict__ sflag, int delta)
 {
     extern __shared__ double vs[]; // [lds_doubles] staging of mstep_state | og[DP] | red[MSF_THREADS]
     double *og = vs + lds_doubles, *red = og + DP;
@@ -244,7 +244,7 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
         }
         __syncthreads();
     }
-    mstep_state(N, M, D, stats, norm2pi, A, c, mean, inv_var, det, wk, logwk, logA, lds_doubles, vs);
+    mstep_state(N, M, D, stats, norm2pi, A, c, mean, inv_var, det, wk, logwk, logA, lds_doubles, vs, delta);
     __syncthreads(); // the state's new parameters (global) and og (LDS) are visible to the block
     const int w = tid >> 6, l = tid & 63;
     const int gp0 = i * Mp, gp1 = (i == N - 1) ? NT * 16 : (i + 1) * Mp;

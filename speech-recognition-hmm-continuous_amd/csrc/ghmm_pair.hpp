@@ -99,11 +99,15 @@ __global__ void __launch_bounds__(WAVE)
 k_scan_pair(int N, int U, int only, const double *__restrict__ A, const double *__restrict__ b,
             const long long *__restrict__ off, double *__restrict__ alpha, double *__restrict__ scale,
             double *__restrict__ sinv, const double *__restrict__ lognorm, double *__restrict__ loglik,
-            double *__restrict__ wrow, double *__restrict__ sb, double *__restrict__ sink)
+            double *__restrict__ wrow, double *__restrict__ sb, double *__restrict__ sink,
+            const int *__restrict__ order)
 {
-    const int u = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    // the wave's 4 (or 1) utterances are neighbours in the corpus' length order (longest
+    // first): equal work inside a wave, the long chains start first
+    const int slot = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
-    if (u >= U) return;
+    if (slot >= U) return;
+    const int u = order[slot];
     const int dir = only >= 0 ? only : (int)blockIdx.y;
     if (dir == 0) {
         // with the backward direction alongside, k_combine follows and takes the logs of log P
@@ -279,12 +283,15 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
           const double *__restrict__ wrow, const double *__restrict__ sb, double *__restrict__ beta,
           double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
           double *__restrict__ part_denc, double *__restrict__ sink,
-          const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk)
+          const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
+          const int *__restrict__ order)
 {
-    const int q = blockIdx.x * (WAVE / L) + threadIdx.x / L;
+    const int qs = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
-    const int u = q / CB_CH, k = q % CB_CH;
-    if (u >= U) return;
+    const int k = qs % CB_CH;
+    if (qs / CB_CH >= U) return;
+    const int u = order[qs / CB_CH]; // longest utterances first
+    const int q = u * CB_CH + k;     // partial-sum slot of (utterance, chunk)
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     const bool act = i < N;

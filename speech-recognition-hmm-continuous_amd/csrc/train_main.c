@@ -13,6 +13,15 @@
  *   - [initial_model] works (the reference reads argv[argc], a NULL, TF:218);
  *   - param_number must be 1 (every BASELINE configuration);
  *   - no MAX_* capacity limits.
+ *
+ * Several GPUs: start one process per GPU with
+ *     GHMM_WORLD=<ranks> GHMM_RANK=<0..ranks-1> GHMM_COMM_ID=<a path unique to the job>
+ *     [GHMM_DEVICE=<gpu index, default = rank>]
+ * and the same argv.  Every rank reads the list, takes its length-balanced share of the
+ * utterances (ghmm_shard_balanced), runs the E-step on it, and the ranks sum the statistics
+ * with ONE RCCL all-reduce per iteration (ghmm_stats_allreduce); every rank applies the same
+ * M-step; rank 0 writes the model and the report.  (GHMM_WORLD=1 with GHMM_COMM_ID set runs
+ * the same code path over a one-rank communicator.)
  */
 #include "ghmm.h"
 
@@ -30,6 +39,12 @@ static void die(const char *what, int rc)
     const char *d = ghmm_last_error();
     printf("%s: %s \n", what, (d && *d) ? d : ghmm_strerror(rc));
     exit(1);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
 }
 
 static void usage(void)
@@ -85,6 +100,18 @@ int main(int argc, char **argv)
     }
     report_name(output, text_file, sizeof text_file);
 
+    const int world = env_int("GHMM_WORLD", 1), rank = env_int("GHMM_RANK", 0);
+    const char *comm_id = getenv("GHMM_COMM_ID");
+    if (world < 1 || rank < 0 || rank >= world) {
+        printf("GHMM_RANK=%d GHMM_WORLD=%d: bad rank layout \n", rank, world);
+        exit(1);
+    }
+    if (world > 1 && !(comm_id && *comm_id)) {
+        printf("GHMM_WORLD=%d needs GHMM_COMM_ID=<path> for the rendezvous \n", world);
+        exit(1);
+    }
+    const int device = env_int("GHMM_DEVICE", world > 1 ? rank : 0);
+
     /* every utterance is read once and stays resident */
     FILE *fl = fopen(list, "r");
     if (!fl) {
@@ -92,13 +119,51 @@ int main(int argc, char **argv)
         exit(1);
     }
     char path[4096];
+    char **files = NULL;
+    int n_files = 0, cap_f = 0, rc;
+    while (fscanf(fl, "%4095s", path) == 1) {
+        if (n_files == cap_f) {
+            cap_f = cap_f ? cap_f * 2 : 64;
+            files = (char **)realloc(files, (size_t)cap_f * sizeof(char *));
+            if (!files) die("memory", GHMM_ERR_ALLOC);
+        }
+        files[n_files] = strdup(path);
+        if (!files[n_files++]) die("memory", GHMM_ERR_ALLOC);
+    }
+    fclose(fl);
+    if (n_files == 0) {
+        printf("no training utterances in %s \n", list);
+        exit(1);
+    }
+    /* this rank's share: all files, or the length-balanced shard (lengths from the file sizes) */
+    int32_t *mine = (int32_t *)malloc((size_t)n_files * sizeof(int32_t));
+    int n_mine = n_files;
+    if (!mine) die("memory", GHMM_ERR_ALLOC);
+    if (world > 1) {
+        int32_t *all_len = (int32_t *)malloc((size_t)n_files * sizeof(int32_t));
+        if (!all_len) die("memory", GHMM_ERR_ALLOC);
+        for (int k = 0; k < n_files; k++) {
+            int d, T;
+            if ((rc = ghmm_perfil_stat(files[k], &d, &T))) die("reading", rc);
+            all_len[k] = T;
+        }
+        if ((rc = ghmm_shard_balanced(all_len, n_files, rank, world, mine, &n_mine))) die("sharding", rc);
+        free(all_len);
+        if (n_mine == 0) {
+            printf("rank %d of %d has no utterances (%d in %s) \n", rank, world, n_files, list);
+            exit(1);
+        }
+    } else {
+        for (int k = 0; k < n_files; k++) mine[k] = k;
+    }
     double *X = NULL;
     int32_t *len = NULL;
     size_t frames = 0, cap = 0;
-    int n_utt = 0, cap_u = 0, D = 0, rc;
-    while (fscanf(fl, "%4095s", path) == 1) {
+    int n_utt = 0, cap_u = 0, D = 0;
+    for (int k = 0; k < n_mine; k++) {
         int d, T;
         double *x;
+        snprintf(path, sizeof path, "%s", files[mine[k]]);
         if ((rc = ghmm_perfil_read(path, &d, &T, &x))) die("reading", rc);
         if (n_utt == 0) D = d;
         if (d != D) {
@@ -119,11 +184,9 @@ int main(int argc, char **argv)
         len[n_utt++] = T;
         frames += (size_t)T;
     }
-    fclose(fl);
-    if (n_utt == 0) {
-        printf("no training utterances in %s \n", list);
-        exit(1);
-    }
+    for (int k = 0; k < n_files; k++) free(files[k]);
+    free(files);
+    free(mine);
 
     ghmm_host_model hm;
     memset(&hm, 0, sizeof hm);
@@ -131,7 +194,10 @@ int main(int argc, char **argv)
     ghmm_model *model;
     ghmm_corpus *corpus;
     ghmm_stats *stats;
-    if ((rc = ghmm_ctx_create(0, NULL, &ctx))) die("GPU context", rc);
+    ghmm_comm *comm = NULL;
+    if ((rc = ghmm_ctx_create(device, NULL, &ctx))) die("GPU context", rc);
+    if (comm_id && *comm_id && (rc = ghmm_comm_create_file(ctx, comm_id, rank, world, 300.0, &comm)))
+        die("communicator", rc);
     if ((rc = ghmm_corpus_create(ctx, X, len, n_utt, D, &corpus))) die("corpus", rc);
     if (initial) {
         if ((rc = ghmm_hmm_read(initial, &hm))) die("initial model", rc);
@@ -150,10 +216,14 @@ int main(int argc, char **argv)
         if ((rc = ghmm_model_create(ctx, N, M, D, &model))) die("model", rc);
         const char *hi = getenv("GHMM_HOST_INIT");
         if (hi && *hi == '1') {
+            if (world > 1) {
+                printf("GHMM_HOST_INIT=1 needs the whole corpus on one rank \n");
+                exit(1);
+            }
             ghmm_host_model_free(&hm);
             if ((rc = ghmm_init_model(X, len, n_utt, N, M, D, &hm))) die("creating initial model", rc);
             if ((rc = ghmm_model_set(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
-        } else if ((rc = ghmm_model_init(ctx, model, corpus))) {
+        } else if ((rc = ghmm_model_init_comm(ctx, model, corpus, comm))) {
             die("creating initial model", rc);
         }
     }
@@ -170,6 +240,8 @@ int main(int argc, char **argv)
         iteration++;
         printf("\r\nStarting training sequence (%d utterances, %zu frames)", n_utt, frames);
         if ((rc = ghmm_estep(ctx, model, corpus, stats))) die("E-step", rc);
+        /* the one exchange of the iteration: sum of the accumulators over ranks */
+        if (comm && (rc = ghmm_stats_allreduce(ctx, stats, comm))) die("all-reduce", rc);
         if ((rc = ghmm_stats_download(ctx, stats, sv))) die("E-step", rc);
         probab = sv[ns - 2];
         printf("\r\nEnding training sequence");
@@ -182,6 +254,7 @@ int main(int argc, char **argv)
         }
     } while (variation > THRESHOLD);
     printf("\r\nFinal Probability = %f\r\n\r\n", variation);
+    if (comm) n_utt = (int)sv[ns - 1]; /* exemplars of all ranks (TF:320, summed) */
     probab /= (double)n_utt;
 
     if ((rc = ghmm_model_get(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
@@ -196,6 +269,7 @@ int main(int argc, char **argv)
     time(&now);
     strftime(t_end, sizeof t_end, "%d-%h-%Y %X", localtime(&now));
 
+    if (rank != 0) goto done; /* every rank holds the same model; rank 0 writes it */
     if ((rc = ghmm_hmm_write(output, &hm, 8))) die("writing model", rc);
 
     FILE *ft = fopen(text_file, "w");
@@ -223,6 +297,8 @@ int main(int argc, char **argv)
         exit(1);
     }
 
+done:
+    ghmm_comm_destroy(comm);
     ghmm_stats_destroy(ctx, stats);
     ghmm_corpus_destroy(ctx, corpus);
     ghmm_model_destroy(ctx, model);

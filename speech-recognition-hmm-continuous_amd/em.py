@@ -18,6 +18,15 @@ def shard_range(n_utt, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def shard_balanced(lens, rank, world):
+    """Length-balanced shard (sort by T, deal in turn): utterances by
+    decreasing length (ties: lower index first), rank r takes every world-th one starting
+    at r; returned in ascending index order.  Frames per rank differ by at most the longest
+    utterance.  Same result as the C ABI's ghmm_shard_balanced (what the C trainer uses)."""
+    order = sorted(range(len(lens)), key=lambda u: (-int(lens[u]), u))
+    return sorted(order[rank::world])
+
+
 class EMDriver:
     """One EM iteration = backend.estep -> all_reduce(stats) -> backend.mstep.
 

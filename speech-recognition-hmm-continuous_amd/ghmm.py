@@ -58,6 +58,15 @@ SYMBOLS = {
     "ghmm_model_set": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp], True),
     "ghmm_model_get": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp], True),
     "ghmm_model_init": (C.c_int, [_vp, _vp, _vp], True),
+    "ghmm_model_init_comm": (C.c_int, [_vp, _vp, _vp, _vp], True),
+    "ghmm_comm_unique_id": (C.c_int, [_vp], True),
+    "ghmm_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)], True),
+    "ghmm_comm_create_file": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_double,
+                                        C.POINTER(_vp)], True),
+    "ghmm_comm_destroy": (None, [_vp], True),
+    "ghmm_comm_rank": (C.c_int, [_vp], True),
+    "ghmm_comm_size": (C.c_int, [_vp], True),
+    "ghmm_stats_allreduce": (C.c_int, [_vp, _vp, _vp], True),
     "ghmm_model_dims": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)], True),
     "ghmm_corpus_create": (C.c_int, [_vp, _dp, _ip, C.c_int, C.c_int, C.POINTER(_vp)], True),
@@ -77,6 +86,7 @@ SYMBOLS = {
     "ghmm_backward": (C.c_int, [_vp, _vp, _vp], True),
     "ghmm_accumulate": (C.c_int, [_vp, _vp, _vp, _vp], True),
     "ghmm_fetch": (C.c_int, [_vp, C.c_int, _dp, C.c_size_t], True),
+    "ghmm_fetch_range": (C.c_int, [_vp, C.c_int, C.c_size_t, _dp, C.c_size_t], True),
     "ghmm_estep": (C.c_int, [_vp, _vp, _vp, _vp], True),
     "ghmm_mstep": (C.c_int, [_vp, _vp, _vp], True),
     "ghmm_score": (C.c_int, [_vp, _vp, _vp, _dp], True),
@@ -85,6 +95,9 @@ SYMBOLS = {
     "ghmm_perfil_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(_dp)], False),
     "ghmm_perfil_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dp], False),
+    "ghmm_perfil_stat": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)], False),
+    "ghmm_shard_balanced": (C.c_int, [_ip, C.c_int, C.c_int, C.c_int, _ip, C.POINTER(C.c_int)],
+                            False),
     "ghmm_free": (None, [_vp], False),
     "ghmm_host_model_alloc": (C.c_int, [C.POINTER(HostModelStruct), C.c_int, C.c_int, C.c_int],
                               False),
@@ -223,6 +236,25 @@ def perfil_read(path):
     return X
 
 
+def perfil_stat(path):
+    """(D, T) of a .perfil file from its header and size."""
+    lib = host_lib()
+    D, T = C.c_int(), C.c_int()
+    _check(lib.ghmm_perfil_stat(os.fsencode(path), C.byref(D), C.byref(T)), lib)
+    return D.value, T.value
+
+
+def shard_balanced(lens, rank, world):
+    """ghmm_shard_balanced: this rank's utterance indices (ascending), length-balanced."""
+    lib = host_lib()
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    idx = np.empty((len(lens) + world - 1) // world + 1, dtype=np.int32)
+    n = C.c_int()
+    _check(lib.ghmm_shard_balanced(lens.ctypes.data_as(_ip), len(lens), rank, world,
+                                   idx.ctypes.data_as(_ip), C.byref(n)), lib)
+    return idx[:n.value].copy()
+
+
 def perfil_write(path, X):
     lib = host_lib()
     X = _f64(X)
@@ -346,6 +378,19 @@ class Context:
         _check(self.lib.ghmm_fetch(self.h, which, _d(out), out.size), self.lib)
         return out
 
+    def fetch_range(self, which, first, shape):
+        """doubles [first, first + prod(shape)) of a workspace buffer"""
+        out = np.empty(shape, dtype=np.float64)
+        _check(self.lib.ghmm_fetch_range(self.h, which, int(first), _d(out), out.size), self.lib)
+        return out
+
+    # ---- several GPUs
+    def comm(self, rank=0, world=1, id_bytes=None, path=None, timeout_s=120.0):
+        return Comm(self, rank, world, id_bytes, path, timeout_s)
+
+    def stats_allreduce(self, stats, comm):
+        _check(self.lib.ghmm_stats_allreduce(self.h, stats.h, comm.h), self.lib)
+
     # ---- fused
     def estep(self, model, corpus, stats):
         _check(self.lib.ghmm_estep(self.h, model.h, corpus.h, stats.h), self.lib)
@@ -386,9 +431,12 @@ class Model:
         _check(self.ctx.lib.ghmm_model_set(self.ctx.h, self.h, *(_d(x) for x in hm.arrays())),
                self.ctx.lib)
 
-    def init_from(self, corpus):
-        """creating_initial_model (TF:732) on the device; returns the model as HostModel."""
-        _check(self.ctx.lib.ghmm_model_init(self.ctx.h, self.h, corpus.h), self.ctx.lib)
+    def init_from(self, corpus, comm=None):
+        """creating_initial_model (TF:732) on the device; returns the model as HostModel.
+        `comm`: the corpus is one rank's shard, the k-means sums are all-reduced."""
+        _check(self.ctx.lib.ghmm_model_init_comm(self.ctx.h, self.h, corpus.h,
+                                                 comm.h if comm is not None else None),
+               self.ctx.lib)
         return self.get()
 
     def get(self):
@@ -429,6 +477,39 @@ class Corpus:
     def close(self):
         if self.h:
             self.ctx.lib.ghmm_corpus_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class Comm:
+    """One rank of an RCCL communicator (ghmm_comm_*): the statistics all-reduce in C."""
+
+    def __init__(self, ctx, rank, world, id_bytes=None, path=None, timeout_s=120.0):
+        self.ctx = ctx
+        h = _vp()
+        if path is not None:
+            _check(ctx.lib.ghmm_comm_create_file(ctx.h, os.fsencode(path), rank, world, timeout_s,
+                                                 C.byref(h)), ctx.lib)
+        else:
+            if id_bytes is None:
+                buf = C.create_string_buffer(128)
+                _check(ctx.lib.ghmm_comm_unique_id(buf), ctx.lib)
+                id_bytes = buf.raw
+            buf = C.create_string_buffer(id_bytes, 128)
+            _check(ctx.lib.ghmm_comm_create(ctx.h, buf, rank, world, C.byref(h)), ctx.lib)
+        self.h = h
+        ctx._children.append(self)
+
+    @property
+    def rank(self):
+        return self.ctx.lib.ghmm_comm_rank(self.h)
+
+    @property
+    def size(self):
+        return self.ctx.lib.ghmm_comm_size(self.h)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.ghmm_comm_destroy(self.h)
             self.h = None
 
 

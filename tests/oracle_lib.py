@@ -38,6 +38,8 @@ def lib():
         L.orc_viterbi_lattice.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip]
         L.orc_log_emission.restype = None
         L.orc_log_emission.argtypes = [C.c_int] * 4 + [_dp] * 6
+        L.orc_emission.restype = None
+        L.orc_emission.argtypes = [C.c_int] * 4 + [_dp] * 7
         L.orc_sort_scores.restype = None
         L.orc_sort_scores.argtypes = [C.c_int, _dp, _ip]
         _lib = L
@@ -115,6 +117,16 @@ def log_emission(hm, X):
     lib().orc_log_emission(hm.N, hm.M, hm.D, X.shape[0], _d(X), _d(hm.c), _d(hm.mean),
                            _d(hm.inv_var), _d(hm.det), _d(out))
     return out
+
+
+def emission(hm, X, want_post=False):
+    """calc_symbol_probab over the frames of X (TF:1749-1841): b[T][N] (and post[T][N][M])."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    b = np.zeros((X.shape[0], hm.N))
+    post = np.zeros((X.shape[0], hm.N, hm.M)) if want_post else None
+    lib().orc_emission(hm.N, hm.M, hm.D, X.shape[0], _d(X), _d(hm.c), _d(hm.mean), _d(hm.inv_var),
+                       _d(hm.det), _d(b), _d(post))
+    return (b, post) if want_post else b
 
 
 def viterbi_lattice(A, logb):

@@ -28,20 +28,37 @@ RTOL = 1e-8          # asserted
 NORTH_STAR_RTOL = 1e-5  # the bar
 
 
-def assert_close(got, ref, rtol=RTOL, floor=1e-13, what=""):
-    """|got-ref| <= rtol*|ref| + floor*max|ref|; non-finite entries must agree in kind."""
-    got = np.asarray(got, dtype=np.float64).ravel()
-    ref = np.asarray(ref, dtype=np.float64).ravel()
+def assert_close(got, ref, rtol=RTOL, floor=1e-13, what="", rows=False):
+    """|got-ref| <= rtol*|ref| + floor*scale; non-finite entries must agree in kind.
+    scale = max|ref| over the whole array, or (rows=True: per-frame quantities b, alpha^, beta^,
+    gamma, post, whose frames span tens of decades) over the entry's own frame, so that an
+    entry is only excused when it is 13 decades below the largest value OF ITS FRAME."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if rows and ref.ndim >= 2:
+        r2 = np.abs(ref.reshape(ref.shape[0], -1))
+        r2 = np.where(np.isfinite(r2), r2, 0.0)
+        scale = np.broadcast_to(r2.max(axis=1, keepdims=True), r2.shape).ravel()
+    else:
+        scale = None
+    got, ref = got.ravel(), ref.ravel()
     assert got.shape == ref.shape, what
     fin = np.isfinite(ref)
     assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern differs"
     assert np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)]), f"{what}: inf differs"
     if fin.any():
-        scale = np.abs(ref[fin]).max()
+        sc = np.abs(ref[fin]).max() if scale is None else scale[fin]
         err = np.abs(got[fin] - ref[fin])
-        tol = rtol * np.abs(ref[fin]) + floor * scale
+        tol = rtol * np.abs(ref[fin]) + floor * sc
         worst = (err / np.maximum(tol, 1e-320)).max()
         assert worst <= 1.0, f"{what}: worst error {worst:.3g} x tolerance"
+
+
+def assert_frames(got, ref, what, rtol=RTOL):
+    """Per-frame arrays: every entry against the largest of its own frame (assert_close, rows)."""
+    ref = np.asarray(ref)
+    got = np.asarray(got).reshape(ref.shape)
+    assert_close(got, ref, rtol=rtol, what=what, rows=True)
 
 
 @pytest.fixture(scope="module")
@@ -60,17 +77,17 @@ def test_rows_against_reference_dumps(G, ctx, case):
     model, corpus = ctx.model(case.model0), ctx.corpus(case.X, case.lens)
     F, N, M, D = corpus.frames, case.N, case.M, case.D
     ctx.emission(model, corpus, True)
-    assert_close(ctx.fetch(G.BUF_B, (F, N)), case.frames("b"), what="b")
-    assert_close(ctx.fetch(G.BUF_POST, (F, N * M)), case.frames("post"), what="post")
+    assert_frames(ctx.fetch(G.BUF_B, (F, N)), case.frames("b"), "b")
+    assert_frames(ctx.fetch(G.BUF_POST, (F, N * M)), case.frames("post").reshape(F, -1), "post")
     ctx.forward(model, corpus)
-    assert_close(ctx.fetch(G.BUF_ALPHA, (F, N)), case.frames("alpha"), what="alpha")
-    assert_close(ctx.fetch(G.BUF_SCALE, (F,)), case.frames("scale"), what="scale")
+    assert_frames(ctx.fetch(G.BUF_ALPHA, (F, N)), case.frames("alpha"), "alpha")
+    assert_close(ctx.fetch(G.BUF_SCALE, (F,)), case.frames("scale"), floor=0.0, what="scale")
     assert_close(ctx.fetch(G.BUF_LOGLIK, (case.U,)), case.logliks(), what="loglik")
     ctx.backward(model, corpus)
     beta, scale = case.frames("beta"), case.frames("scale")
-    assert_close(ctx.fetch(G.BUF_BETA, (F, N)), beta, what="beta")
+    assert_frames(ctx.fetch(G.BUF_BETA, (F, N)), beta, "beta")
     gamma_ref = case.frames("alpha") * beta / scale[:, None]
-    assert_close(ctx.fetch(G.BUF_GAMMA, (F, N)), gamma_ref, what="gamma")
+    assert_frames(ctx.fetch(G.BUF_GAMMA, (F, N)), gamma_ref, "gamma")
     stats = ctx.stats(N, M, D)
     ctx.accumulate(model, corpus, stats)
     got, ref = G.split_stats(stats.download(), N, M, D), G.split_stats(case.stats(), N, M, D)
@@ -292,11 +309,11 @@ def test_estep_against_oracle(G, ctx, N, M, D, lens, dense):
     stats = ctx.stats(N, M, D)
     ctx.estep(model, corpus, stats)
     F = corpus.frames
-    assert_close(ctx.fetch(G.BUF_B, (F, N)), ref["b"], what="b")
-    assert_close(ctx.fetch(G.BUF_POST, (F, N * M)), ref["post"], what="post")
-    assert_close(ctx.fetch(G.BUF_ALPHA, (F, N)), ref["alpha"], what="alpha")
-    assert_close(ctx.fetch(G.BUF_BETA, (F, N)), ref["beta"], what="beta")
-    assert_close(ctx.fetch(G.BUF_SCALE, (F,)), ref["scale"], what="scale")
+    assert_frames(ctx.fetch(G.BUF_B, (F, N)), ref["b"], "b")
+    assert_frames(ctx.fetch(G.BUF_POST, (F, N * M)), ref["post"].reshape(F, -1), "post")
+    assert_frames(ctx.fetch(G.BUF_ALPHA, (F, N)), ref["alpha"], "alpha")
+    assert_frames(ctx.fetch(G.BUF_BETA, (F, N)), ref["beta"], "beta")
+    assert_close(ctx.fetch(G.BUF_SCALE, (F,)), ref["scale"], floor=0.0, what="scale")
     assert_close(ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ref["loglik"], what="loglik")
     got, refs = G.split_stats(stats.download(), N, M, D), G.split_stats(ref_stats, N, M, D)
     for k in refs:
@@ -322,9 +339,9 @@ def test_both_kernel_tiers(G, ctx, tier, load_case):
             stats = ctx.stats(case.N, case.M, case.D)
             ctx.estep(model, corpus, stats)
             F = corpus.frames
-            assert_close(ctx.fetch(G.BUF_B, (F, case.N)), case.frames("b"), what=f"{name} b")
-            assert_close(ctx.fetch(G.BUF_POST, (F, case.N * case.M)), case.frames("post"),
-                         what=f"{name} post")
+            assert_frames(ctx.fetch(G.BUF_B, (F, case.N)), case.frames("b"), f"{name} b")
+            assert_frames(ctx.fetch(G.BUF_POST, (F, case.N * case.M)),
+                          case.frames("post").reshape(F, -1), f"{name} post")
             got = G.split_stats(stats.download(), case.N, case.M, case.D)
             ref = G.split_stats(case.stats(), case.N, case.M, case.D)
             for k in ref:
@@ -412,7 +429,7 @@ def test_beta_on_demand_follows_the_model(G, ctx):
     stats = ctx.stats(5, 2, 6)
     _, ref = O.estep(hm, X, lens)
     ctx.estep(model, corpus, stats)
-    assert_close(ctx.fetch(G.BUF_BETA, (corpus.frames, 5)), ref["beta"], what="beta after estep")
+    assert_frames(ctx.fetch(G.BUF_BETA, (corpus.frames, 5)), ref["beta"], "beta after estep")
     ctx.estep(model, corpus, stats)
     ctx.mstep(model, stats)
     with pytest.raises(G.GhmmError):
@@ -733,3 +750,352 @@ def test_two_ranks_on_one_gpu_equal_one_rank(G, ctx):
         assert np.array_equal(a, b)   # identical statistics -> identical redundant M-steps
     for o in (model, corpus, stats):
         o.close()
+
+
+# ------------------------------------------------ fuzz against the oracle (seeded shapes)
+
+def fuzz_estep_case(G, ctx, seed):
+    """E-step + M-step of the default tier against the oracle on one seeded random shape
+    (1-20 states, 1-11 mixtures, 1-44 coefficients, dense or band-diagonal A, band 0..3).
+    profiles/fuzz_oracle.py runs the same body over hundreds of seeds."""
+    rng = np.random.default_rng(9000 + seed)
+    N, M, D = int(rng.integers(1, 21)), int(rng.integers(1, 12)), int(rng.integers(1, 45))
+    # every utterance can reach the last state
+    lens = [int(x) for x in rng.integers(N, N + 120, size=int(rng.integers(1, 7)))]
+    dense, delta = bool(rng.integers(0, 2)), int(rng.integers(0, 4))
+    hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense, seed=seed,
+                             perturb=float(rng.choice([0.02, 0.1, 0.3])))
+    ref_stats, ref = O.estep(hm, X, lens, delta=delta)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    F = corpus.frames
+    ctx.set_option(G.OPT_DELTA, delta)
+    try:
+        stats = ctx.stats(N, M, D)
+        ctx.estep(model, corpus, stats)
+        tag = f"seed {seed} N={N} M={M} D={D} lens={list(map(int, lens))} dense={dense} delta={delta}: "
+        assert_close(ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ref["loglik"], what=tag + "loglik")
+        assert_frames(ctx.fetch(G.BUF_B, (F, N)), ref["b"], tag + "b")
+        assert_frames(ctx.fetch(G.BUF_ALPHA, (F, N)), ref["alpha"], tag + "alpha")
+        assert_frames(ctx.fetch(G.BUF_BETA, (F, N)), ref["beta"], tag + "beta")
+        assert_close(stats.download(), ref_stats, what=tag + "stats")
+        ctx.mstep(model, stats)
+        new, ref_new = model.get(), O.mstep(hm, ref_stats)
+        for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), new.arrays(), ref_new.arrays()):
+            assert_close(a, b, rtol=1e-7, what=tag + "mstep." + nm)
+    finally:
+        ctx.set_option(G.OPT_DELTA, 1)
+        for o in (model, corpus):
+            o.close()
+
+
+def fuzz_viterbi_case(G, ctx, seed):
+    """Viterbi state sequences (bit-identical) and forward scores against the oracle on one
+    seeded random shape; profiles/fuzz_viterbi.py runs it over more seeds.  Returns the number
+    of utterances checked."""
+    rng = np.random.default_rng(7000 + seed)
+    N, M, D = int(rng.integers(1, 21)), int(rng.integers(1, 12)), int(rng.integers(1, 45))
+    lens = [int(x) for x in rng.integers(1, 150, size=int(rng.integers(1, 6)))]
+    dense = bool(rng.integers(0, 2))
+    hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense, seed=seed,
+                             perturb=float(rng.choice([0.02, 0.1, 0.3])))
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    try:
+        path, score = ctx.viterbi(model, corpus)
+        fwd = ctx.score(model, corpus)   # calc_alpha + calc_probability alone (the recogniser's path)
+        o = 0
+        for u, Tn in enumerate(lens):
+            tag = f"seed {seed} utt {u}: N={N} M={M} D={D} T={Tn} dense={dense}"
+            p, sc = O.viterbi(hm, X[o:o + Tn])
+            assert np.array_equal(path[o:o + Tn], p), tag + ": path differs"
+            assert (score[u] == sc) if not np.isfinite(sc) else abs(score[u] - sc) <= 1e-10 * abs(sc), \
+                tag + f": score {score[u]!r} vs {sc!r}"
+            fs = O.score(hm, X[o:o + Tn])
+            assert ((np.isnan(fs) and np.isnan(fwd[u])) or fwd[u] == fs
+                    or abs(fwd[u] - fs) <= 1e-10 * abs(fs)), tag + f": forward score {fwd[u]!r} vs {fs!r}"
+            o += Tn
+    finally:
+        model.close()
+        corpus.close()
+    return len(lens)
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_fuzz_estep_against_oracle(G, ctx, seed):
+    fuzz_estep_case(G, ctx, seed)
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_fuzz_viterbi_against_oracle(G, ctx, seed):
+    fuzz_viterbi_case(G, ctx, seed)
+
+
+# ------------------------------------------------------------------- boundary
+
+def test_two_contexts_two_host_threads(G, ctx):
+    """SURVEY §8(b) threading row: one context per host thread, no global mutable state.  Two
+    contexts (own streams; on a one-GPU box both on device 0) run E-steps concurrently from
+    two threads — kernels that need the raised LDS limit included — and each must match the
+    oracle; the contexts are created on the threads that use them."""
+    import threading
+    cases = [synth_case(G, 10, 8, 39, [120, 77, 64, 90]), synth_case(G, 7, 3, 39, [100, 61, 16], first=9)]
+    refs = [O.estep(hm, X, lens, dumps=False)[0] for hm, X, lens in cases]
+    out, errs = [None, None], []
+
+    def work(k):
+        try:
+            hm, X, lens = cases[k]
+            c = G.Context(0)
+            try:
+                model, corpus = c.model(hm), c.corpus(X, lens)
+                stats = c.stats(hm.N, hm.M, hm.D)
+                for _ in range(5):
+                    c.estep(model, corpus, stats)
+                out[k] = stats.download()
+                path, _ = c.viterbi(model, corpus)
+                assert path.shape == (int(np.sum(lens)),)
+            finally:
+                c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        assert_close(out[k], refs[k], what=f"thread {k} statistics")
+
+
+def test_stale_workspace_is_refused(G, ctx):
+    """beta^ on demand is rebuilt from the E-step's alpha^ / W: once another call has rewritten
+    the workspace (a score of another corpus) ghmm_fetch must refuse, not return garbage;
+    ghmm_forward must refuse the emission densities of another model of the same shape."""
+    hm, X, lens = synth_case(G, 5, 2, 6, [40, 25])
+    hm2, X2, lens2 = synth_case(G, 5, 2, 6, [40, 25], perturb=0.2, first=4)
+    model, corpus, other = ctx.model(hm), ctx.corpus(X, lens), ctx.corpus(X2, lens2)
+    model2 = ctx.model(hm2)
+    stats = ctx.stats(5, 2, 6)
+    ctx.estep(model, corpus, stats)
+    ctx.score(model, other)
+    with pytest.raises(G.GhmmError):
+        ctx.fetch(G.BUF_BETA, (corpus.frames, 5))
+    ctx.emission(model, corpus, True)
+    with pytest.raises(G.GhmmError):
+        ctx.forward(model2, corpus)        # b belongs to `model`
+    with pytest.raises(G.GhmmError):
+        ctx.forward(model, other)          # ... and to `corpus`
+    ctx.forward(model, corpus)
+    for o in (model, model2, corpus, other, stats):
+        o.close()
+
+
+def test_mstep_reads_the_transition_band_only(G, ctx):
+    """ghmm_mstep takes num_a inside i <= j <= i + delta (the only entries TF:1601 ever
+    accumulates); whatever else an uploaded vector holds there is ignored, so a band-diagonal
+    A stays band-diagonal and the band-only combine pass stays valid."""
+    hm, X, lens = synth_case(G, 6, 2, 5, [50, 41, 33])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(6, 2, 5)
+    ctx.estep(model, corpus, stats)
+    v = stats.download()
+    ref_new = O.mstep(hm, v)
+    dirty = v.copy()
+    na = dirty[:36].reshape(6, 6)
+    na[np.tril_indices(6, -1)] = 0.37       # below the diagonal
+    na[np.triu_indices(6, 2)] = 0.11        # beyond i + 1
+    stats.upload(dirty)
+    ctx.mstep(model, stats)
+    new = model.get()
+    for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), new.arrays(), ref_new.arrays()):
+        assert_close(a, b, rtol=1e-12, floor=0.0, what="mstep." + nm)
+    # and the next E-step (band-only combine) agrees with the oracle on that model
+    ctx.estep(model, corpus, stats)
+    ref2, _ = O.estep(ref_new, X, lens, dumps=False)
+    assert_close(stats.download(), ref2, what="E-step after the masked M-step")
+    for o in (model, corpus, stats):
+        o.close()
+
+
+def test_length_order_and_balanced_shards(G, ctx):
+    """Utterances are packed four to a wave in length order (longest first): results must not
+    depend on it.  A corpus and its shuffled copy give the same per-utterance log P and the
+    same statistics; the length-balanced shards of em.shard_balanced add up to the whole."""
+    em = __import__("ghmm_amd").em
+    rng = np.random.default_rng(5)
+    lens = rng.integers(100, 501, size=37).astype(np.int32)    # T ~ U[100, 500] (SURVEY §8(d))
+    hm, X, lens = synth_case(G, 10, 8, 39, lens)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    ctx.estep(model, corpus, stats)
+    full = stats.download()
+    ll = ctx.fetch(G.BUF_LOGLIK, (len(lens),))
+    ref, dump = O.estep(hm, X, lens)
+    assert_close(full, ref, what="ragged corpus vs oracle")
+    assert_close(ll, dump["loglik"], what="ragged loglik")
+    perm = rng.permutation(len(lens))
+    Xp = np.concatenate([X[off[u]:off[u + 1]] for u in perm])
+    cp = ctx.corpus(Xp, lens[perm])
+    ctx.estep(model, cp, stats)
+    assert_close(stats.download(), full, rtol=1e-11, what="shuffled corpus")
+    assert_close(ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ll[perm], rtol=1e-13, what="shuffled loglik")
+    path, score = ctx.viterbi(model, cp)
+    path0, score0 = ctx.viterbi(model, corpus)
+    assert np.array_equal(score, score0[perm])
+    offp = np.concatenate([[0], np.cumsum(lens[perm])])
+    for k, u in enumerate(perm):
+        assert np.array_equal(path[offp[k]:offp[k + 1]], path0[off[u]:off[u + 1]])
+    acc = np.zeros_like(full)
+    frames = []
+    for r in range(3):
+        idx = em.shard_balanced(lens, r, 3)
+        assert list(idx) == list(G.shard_balanced(lens, r, 3))
+        c = ctx.corpus(np.concatenate([X[off[u]:off[u + 1]] for u in idx]), lens[idx])
+        ctx.estep(model, c, stats)
+        acc += stats.download()
+        frames.append(int(lens[idx].sum()))
+        c.close()
+    assert max(frames) - min(frames) <= lens.max()
+    assert_close(acc, full, rtol=1e-11, what="balanced shards add up")
+    for o in (model, corpus, cp, stats):
+        o.close()
+
+
+# ------------------------------------------------------- the C-side collective (RCCL)
+
+def test_rccl_allreduce_one_rank_communicator(G, ctx, tmp_path):
+    """ghmm_comm_* / ghmm_stats_allreduce on a real RCCL communicator of ONE rank (all a
+    one-GPU box can hold: RCCL refuses two ranks on one device): the sum over ranks of a vector
+    is the vector; ghmm_model_init_comm over it equals ghmm_model_init; the id-through-a-file
+    rendezvous works and removes its file."""
+    hm, X, lens = synth_case(G, 10, 8, 39, [90, 120, 65, 77])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    comm = ctx.comm(0, 1)
+    assert (comm.rank, comm.size) == (0, 1)
+    ctx.estep(model, corpus, stats)
+    before = stats.download()
+    ctx.stats_allreduce(stats, comm)
+    assert np.array_equal(stats.download(), before)
+    ctx.mstep(model, stats)                       # E-step -> all-reduce -> M-step on one stream
+    ref_new = O.mstep(hm, O.estep(hm, X, lens, dumps=False)[0])
+    for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), model.get().arrays(), ref_new.arrays()):
+        assert_close(a, b, rtol=1e-7, what="mstep after all-reduce: " + nm)
+    a = model.init_from(corpus)
+    b = model.init_from(corpus, comm)
+    for x, y in zip(a.arrays(), b.arrays()):
+        assert np.array_equal(x, y)
+    comm.close()
+    idfile = os.path.join(str(tmp_path), "comm.id")
+    c2 = ctx.comm(0, 1, path=idfile)
+    assert not os.path.exists(idfile)
+    ctx.stats_allreduce(stats, c2)
+    c2.close()
+    for o in (model, corpus, stats):
+        o.close()
+
+
+def test_train_command_line_multi_rank_mode(G, whole, tmp_path):
+    """The C trainer's rank / world mode (GHMM_WORLD, GHMM_RANK, GHMM_COMM_ID, GHMM_DEVICE) over a
+    one-rank RCCL communicator: same report and model as the plain run."""
+    exe = os.path.join(PKG_DIR, "bin", "hmm-continuous-train-fs")
+    files = [os.path.join(GOLDEN, "perfil", fn) for fn in whole["mean_list"]]
+    lst = _write_lists(str(tmp_path), files, "parameters.txt")
+    outs = []
+    for tag, env in (("plain", {}), ("comm", {"GHMM_WORLD": "1", "GHMM_RANK": "0", "GHMM_DEVICE": "0",
+                                              "GHMM_COMM_ID": os.path.join(str(tmp_path), "id")})):
+        out = os.path.join(str(tmp_path), tag + "_all13.hmm")
+        p = subprocess.run([exe, "all13", "6", "1", "3", lst, out], stdout=subprocess.PIPE,
+                           env={**os.environ, **env})
+        assert p.returncode == 0, p.stdout.decode()
+        rep = [l for l in open(out[:-4] + ".txt").read().split("\n")
+               if not l.startswith(("model file", "starting time", "ending time", "cpu time"))]
+        outs.append((rep, G.HostModel.read(out)))
+    assert outs[0][0] == outs[1][0]
+    exp = whole["train_all13_m3"]
+    assert f"number of iterations: {exp['iterations']} " in outs[1][0]
+    assert "number of exemplars in training sequence: 13 " in outs[1][0]
+    for a, b in zip(outs[0][1].arrays(), outs[1][1].arrays()):
+        assert np.array_equal(a, b)
+    # a rank layout without a rendezvous path is refused
+    p = subprocess.run([exe, "all13", "6", "1", "3", lst, os.path.join(str(tmp_path), "x.hmm")],
+                       stdout=subprocess.PIPE, env={**os.environ, "GHMM_WORLD": "2", "GHMM_RANK": "1"})
+    assert p.returncode == 1 and b"GHMM_COMM_ID" in p.stdout
+
+
+# ------------------------- BASELINE configs[4]: 2 000 tied states x 16 mixtures, 1 M frames
+
+def _config5_model(G, N=2000, M=16, D=39, seed=11):
+    """A triphone-scale codebook: N x M Gaussians around N state centres (numpy, seeded)."""
+    rng = np.random.default_rng(seed)
+    centre = rng.normal(0.0, 2.0, size=(N, 1, D))
+    mean = centre + rng.normal(0.0, 0.7, size=(N, M, D))
+    var = rng.uniform(0.5, 1.5, size=(N, M, D)) ** 2
+    c = rng.uniform(0.5, 1.5, size=(N, M))
+    c /= c.sum(1, keepdims=True)
+    A = np.zeros((N, N))
+    return G.HostModel(A, c, mean, 1.0 / var, var.prod(axis=2)), centre[:, 0, :]
+
+
+def _config5_frames(centre, F, seed, chunk=1 << 16):
+    """Frames near randomly chosen state centres, generated in chunks (1 M x 39 doubles)."""
+    rng = np.random.default_rng(seed)
+    X = np.empty((F, centre.shape[1]))
+    for lo in range(0, F, chunk):
+        n = min(chunk, F - lo)
+        X[lo:lo + n] = centre[rng.integers(0, centre.shape[0], n)] + rng.normal(0.0, 1.2, (n, centre.shape[1]))
+    return X
+
+
+def test_config5_emission_slice_against_oracle(G, ctx):
+    """calc_symbol_probab / calc_gaus (TF:1749-1841) at N = 2 000, M = 16, D = 39 (emission
+    only: the reference's stack arrays cannot hold this model as a program):
+    b of a 96-frame slice (one ragged tile) against the oracle's orc_emission, entry by entry
+    relative to each frame's largest density."""
+    hm, centre = _config5_model(G)
+    X = _config5_frames(centre, 96 + 7, seed=1)
+    lens = np.array([len(X)], dtype=np.int32)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    ctx.emission(model, corpus, False)
+    got = ctx.fetch(G.BUF_B, (len(X), hm.N))
+    ref = O.emission(hm, X)
+    assert np.isfinite(ref).all() and (ref.max(axis=1) > 0).all()
+    assert_frames(got, ref, "config 5 b")
+    for o in (model, corpus):
+        o.close()
+
+
+def test_config5_full_size_properties(G, ctx):
+    """The full configuration: 1 M frames x 2 000 states (b = 16 GB in HBM).  Properties that
+    hold at any size — every b finite and >= 0, every frame with a positive density — checked
+    over the whole output in blocks, and blocks of frames equal to what a SEPARATE launch over
+    just those frames computes (which the slice test ties to the oracle)."""
+    F, N = 1_000_000, 2000
+    hm, centre = _config5_model(G)
+    X = _config5_frames(centre, F, seed=2)
+    model = ctx.model(hm)
+    corpus = ctx.corpus(X, np.array([F], dtype=np.int32))
+    ctx.emission(model, corpus, False)
+    keep = {}
+    blk = 50_000
+    mins, maxs = [], []
+    for lo in range(0, F, blk):
+        b = ctx.fetch_range(G.BUF_B, lo * N, (blk, N))
+        assert np.isfinite(b).all() and (b >= 0.0).all(), f"frames {lo}..{lo + blk}"
+        rowmax = b.max(axis=1)
+        assert (rowmax > 0.0).all(), f"a frame without any density in {lo}..{lo + blk}"
+        mins.append(rowmax.min()); maxs.append(rowmax.max())
+        for f0 in (0, 499_984, 999_904):      # first tile, a middle tile, the last 96 frames
+            if lo <= f0 < lo + blk:
+                keep[f0] = b[f0 - lo:f0 - lo + 96].copy()
+    corpus.close()
+    for f0, bfull in keep.items():
+        c = ctx.corpus(X[f0:f0 + 96], np.array([96], dtype=np.int32))
+        ctx.emission(model, c, False)
+        assert np.array_equal(ctx.fetch(G.BUF_B, (96, N)), bfull), f"frames {f0}.. differ between launches"
+        ref = O.emission(hm, X[f0:f0 + 96])
+        assert_frames(bfull, ref, f"config 5 full run, frames {f0}..")
+        c.close()
+    model.close()

@@ -18,12 +18,12 @@ def test_abi_library_exports_every_declared_symbol(G):
     lib = ctypes.CDLL(G.HIP_LIB)
     hdr = open(os.path.join(ROOT, "include", "ghmm.h")).read()
     declared = set(re.findall(r"\b(ghmm_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"ghmm_ctx", "ghmm_model", "ghmm_corpus", "ghmm_stats", "ghmm_host_model"}
-    assert len(declared) >= 45
+    declared -= {"ghmm_ctx", "ghmm_model", "ghmm_corpus", "ghmm_stats", "ghmm_host_model", "ghmm_comm"}
+    assert len(declared) >= 57
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ghmm.h but not exported"
     assert set(G.SYMBOLS) == declared
-    assert lib.ghmm_version() == 100
+    assert lib.ghmm_version() == 200
 
 
 def test_no_cpu_fallback(G):
@@ -43,15 +43,22 @@ def test_no_cpu_fallback(G):
 
 def test_product_does_not_touch_the_oracle():
     """The oracle is test infrastructure: nothing under the package or include/ may include,
-    link, dlopen or import it (comments may mention it)."""
+    link, dlopen or import it (comments may mention it).  The one dlopen in the product loads
+    RCCL for the statistics all-reduce (ghmm_comm_*): every shared-object name the library
+    can pass to it must be an RCCL name."""
     import re
-    bad = re.compile(r'libghmm_oracle|oracle_lib|#\s*include\s*[<"][^>"]*oracle|dlopen|orc_[a-z_]+\s*\(')
+    bad = re.compile(r'libghmm_oracle|oracle_lib|#\s*include\s*[<"][^>"]*oracle|orc_[a-z_]+\s*\(')
     for root in (PKG_DIR, os.path.join(ROOT, "include")):
         for d, _, files in os.walk(root):
             for fn in files:
                 if fn.endswith((".c", ".hip", ".hpp", ".h", ".py")) or fn == "Makefile":
                     txt = open(os.path.join(d, fn), errors="replace").read()
                     assert not bad.search(txt), f"{fn} reaches into oracle/"
+                    if "dlopen" in txt:
+                        assert fn == "ghmm_hip.hip", f"{fn} calls dlopen"
+                        sonames = re.findall(r'"([^"\n]*\.so[^"\n]*)"', txt)
+                        assert sonames and all("rccl" in n for n in sonames), sonames
+                        assert re.findall(r'getenv\("([A-Z_]+)"\)', txt) == ["GHMM_RCCL_LIB"]
     out = subprocess.run(["ldd", os.path.join(PKG_DIR, "libghmm_hip.so")], stdout=subprocess.PIPE)
     assert b"ghmm_oracle" not in out.stdout
     for exe in ("hmm-continuous-train-fs", "recognition-continuous-test-fs"):
@@ -160,3 +167,37 @@ def test_stats_layout_matches_header(G):
     assert s["num_a"].shape == (3, 3) and s["num_mu"].shape == (3, 2, 4)
     assert s["loglik"] == v[-2] and s["n_utt"] == v[-1]
     assert G.stats_len(10, 8, 39) == 6442 and G.stats_len(10, 64, 39) == 50682
+
+
+def test_length_balanced_shards(G):
+    """ghmm_shard_balanced (C, used by the trainer's rank mode) = em.shard_balanced (bench /
+    torch path): sort by length, deal in turn; every utterance lands on exactly
+    one rank and the ranks' frame counts differ by at most the longest utterance."""
+    from _load import load_pkg
+    em = load_pkg().em
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 5, 17, 1000):
+        lens = rng.integers(1, 500, n).astype(np.int32)
+        for world in (1, 2, 3, 8):
+            seen, frames = [], []
+            for r in range(world):
+                a = list(G.shard_balanced(lens, r, world))
+                assert a == em.shard_balanced(lens, r, world) and a == sorted(a)
+                seen += a
+                frames.append(int(lens[a].sum()))
+            assert sorted(seen) == list(range(n))
+            if n:
+                assert max(frames) - min(frames) <= lens.max()
+    # equal lengths: contiguous-free but equal counts
+    assert [len(G.shard_balanced(np.full(1000, 300), r, 8)) for r in range(8)] == [125] * 8
+
+
+def test_perfil_stat_reads_header_and_size(G, tmp_path):
+    X = np.arange(35.0).reshape(7, 5)
+    p = os.path.join(str(tmp_path), "a.perfil")
+    G.perfil_write(p, X)
+    assert G.perfil_stat(p) == (5, 7)
+    D, T = G.perfil_stat(os.path.join(GOLDEN, "perfil", "mean_vc_186_f_03_ap_0225.perfil"))
+    assert D == 9 and T == len(G.perfil_read(os.path.join(GOLDEN, "perfil", "mean_vc_186_f_03_ap_0225.perfil")))
+    with pytest.raises(G.GhmmError):
+        G.perfil_stat(os.path.join(str(tmp_path), "missing.perfil"))
