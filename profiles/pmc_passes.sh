@@ -13,6 +13,6 @@ for grp in \
   "FETCH_SIZE GRBM_GUI_ACTIVE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
 done
 ls "$OUT"/pass*/*/ | head -20

@@ -110,6 +110,7 @@ struct ghmm_model {
     // relative to the tile's offset; sflag: like anyflag, for the statistics (global offset)
     double *otile = nullptr, *dtile = nullptr, *condt = nullptr;
     int *tshift = nullptr, *sflag = nullptr, *tnext = nullptr; // tnext: the choice for the next preparation
+    int *tfull = nullptr; // [NT] the tile's slots are 16 consecutive real Gaussians, even start, G even
     bool banded = false; // A as last set from the host has a_ij = 0 unless j = i or i + 1
     int epoch = 0; // preparation count; anyflag[0] == epoch: this model holds an ill-conditioned Gaussian
     int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
@@ -506,7 +507,8 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
                 (rc = dev_alloc(&m->oglob, (size_t)m->DP)) || (rc = dev_alloc(&m->anyflag, 1)) ||
                 (rc = dev_alloc(&m->otile, (size_t)m->NT * m->DP)) || (rc = dev_alloc(&m->dtile, (size_t)m->NT * m->DP)) ||
                 (rc = dev_alloc(&m->condt, (size_t)m->NT * 16)) || (rc = dev_alloc(&m->tshift, (size_t)m->NT)) ||
-                (rc = dev_alloc(&m->sflag, 1)) || (rc = dev_alloc(&m->tnext, (size_t)m->NT))) {
+                (rc = dev_alloc(&m->sflag, 1)) || (rc = dev_alloc(&m->tnext, (size_t)m->NT)) ||
+                (rc = dev_alloc(&m->tfull, (size_t)m->NT))) {
                 ghmm_model_destroy(ctx, m);
                 return rc;
             }
@@ -518,6 +520,15 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
             if (e == hipSuccess) e = hipMemsetAsync(m->sflag, 0, sizeof(int), ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(m->anyflag, 0, sizeof(int), ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(m->tnext, 0, (size_t)m->NT * sizeof(int), ctx->stream);
+            // which tiles hold 16 consecutive real Gaussians (a property of N, M and the padding)
+            std::vector<int> tf((size_t)m->NT, 0);
+            for (int t = 0; t < m->NT; t++) {
+                const long long gp0 = 16ll * t, gp1 = gp0 + 15;
+                tf[t] = (Mp == M && gp1 / Mp < N && (G % 2) == 0) ? 1 : 0; // no padding: g = gp, even start
+            }
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(m->tfull, tf.data(), tf.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // tf is a local
             if (e != hipSuccess) {
                 ghmm_set_error("ghmm_model_create: hipMemsetAsync failed: %s", hipGetErrorString(e));
                 ghmm_model_destroy(ctx, m);
@@ -545,7 +556,7 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
     }
     void *bufs[] = {m->A,  m->c,    m->mean, m->inv_var, m->det,   m->wk,    m->logwk, m->logA,
                     m->Wm, m->offs, m->wkp,  m->condp,   m->gmap,  m->oglob, m->condg, m->anyflag,
-                    m->logwkp, m->otile, m->dtile, m->condt, m->tshift, m->sflag, m->tnext};
+                    m->logwkp, m->otile, m->dtile, m->condt, m->tshift, m->sflag, m->tnext, m->tfull};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete m;
@@ -859,21 +870,18 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         int rc;
         const long long ntf = (c->F + 15) / 16;
         const int chunks = (m->NT + m->TC - 1) / m->TC;
-        const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
-                             (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
-                             (size_t)m->TC * 16 * 32 + // wk + cursor tables
-                             (size_t)m->TC * (m->DP + 1) * 8; // per-tile offsets
-        long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
+        const int wv = ems_waves(m->Mp);
+        const size_t lds_s = ems_lds_bytes(m->TC, m->DP, wv);
+        long long gxs = (ntf + wv - 1) / wv;
         if (gxs > ctx->cus) gxs = ctx->cus;
         kscope ks(ctx, GHMM_K_EMISSION);
 #define GHMM_EML(MP, IDX)                                                                         \
     do {                                                                                          \
         if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, 2>))) return rc;          \
         hipLaunchKernelGGL((k_emission_sched<20, MP, 2>), dim3((unsigned)gxs, (unsigned)chunks), \
-                           dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,  \
+                           dim3((unsigned)(wv * WAVE)), lds_s, ctx->stream, m->N, m->M, m->D, m->NT, \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->logwkp, m->gmap, ctx->b,       \
-                           (double *)nullptr, ctx->sink, m->anyflag, m->epoch, m->dtile,          \
-                           m->tshift);                                                            \
+                           (double *)nullptr, m->anyflag, m->epoch, m->dtile, m->tshift, m->tfull); \
     } while (0)
         switch (m->Mp) {
         case 1: GHMM_EML(1, 0); break;
@@ -897,11 +905,9 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         // (anyflag, set on the device by k_prepare_mfma); the generic kernel launched right
         // after it returns at once when it does not — no host round trip either way.
         const bool sched = (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
-        const size_t lds_s = (size_t)m->TC * (m->DP / 2) * 64 * 8 +
-                             (size_t)EMS_WAVES * 16 * (m->DP + 1) * 8 + (size_t)m->DP * 8 +
-                             (size_t)m->TC * 16 * 32 + // wk + cursor tables
-                             (size_t)m->TC * (m->DP + 1) * 8; // per-tile offsets
-        long long gxs = (ntf + EMS_WAVES - 1) / EMS_WAVES;
+        const int wv = ems_waves(m->Mp);
+        const size_t lds_s = ems_lds_bytes(m->TC, m->DP, wv);
+        long long gxs = (ntf + wv - 1) / wv;
         if (gxs > ctx->cus) gxs = ctx->cus;
         {
             kscope ks(ctx, GHMM_K_EMISSION);
@@ -910,9 +916,9 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
     do {                                                                                          \
         if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, PO>))) return rc;         \
         hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
-                           dim3(EMS_WAVES * WAVE), lds_s, ctx->stream, m->N, m->M, m->D, m->NT,   \
+                           dim3((unsigned)(wv * WAVE)), lds_s, ctx->stream, m->N, m->M, m->D, m->NT, \
                            m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap, ctx->b, post,     \
-                           ctx->sink, m->anyflag, m->epoch, m->dtile, m->tshift);                 \
+                           m->anyflag, m->epoch, m->dtile, m->tshift, m->tfull);                  \
     } while (0)
 #define GHMM_EMS2(MP)                                                                             \
     do {                                                                                          \

@@ -27,6 +27,15 @@
 namespace ghmm {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// a 64-bit value that is the same in every lane, moved to scalar registers
+__device__ inline long long uniform64(long long v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned)lo;
+}
 
 constexpr double COND_MAX = 1.0e4; // expanded-form error ~ 4*eps*cond  (<= ~5e-12)
 constexpr int EM_WAVES = 8;        // waves per block of the generic emission kernel
@@ -468,29 +477,58 @@ k_emission_mfma(int N, int M, int Mp, int D, int DP, int NT, int TC, long long F
 // Same computation as k_emission_mfma for the common, well-conditioned case (no
 // ill-conditioned Gaussian anywhere, Mp a power of two <= 64), built for 4 waves per SIMD: sixteen
 // waves per block (one block per CU) share the chunk's B fragments in LDS, every wave
-// keeps x' = x - oglob of its 16 frames in a 5 KB slab and, where registers allow, as A
-// fragments (x', x'^2) for all of the frame tile's Gaussian tiles; the kernel stays under 128
-// VGPRs.  An f64 MFMA and vector-ALU work never overlap on a SIMD; the four
-// waves cover each other's LDS and HBM waits.
+// keeps x' = x - oglob of its 16 frames in a 5 KB slab and, where registers allow, as MFMA
+// operands (x', x'^2) for all of the frame tile's Gaussian tiles; the kernel stays under 128
+// VGPRs.  An f64 MFMA and vector-ALU work never overlap on a SIMD: the
+// kernel's time is MFMA time + vector time, so the epilogue is built to need few vector
+// instructions:
+//   - the product is taken TRANSPOSED (A = Gaussians x k, B = k x frames): a lane then holds
+//     FOUR GAUSSIANS OF ONE FRAME (rows (l>>4) + 4r of column l&15), and the Gaussians of a
+//     tile are placed on the MFMA rows so that those four are neighbours (slot p = 4(l>>4) + r):
+//     the sum over a state's mixtures is 3 additions in the lane (+ one v_permlane16_swap
+//     level for 8 mixtures, + one v_permlane32_swap level for 16), every lane ends up with
+//     its own state's b_i, and a lane's four posteriors are 32 contiguous bytes of the
+//     posterior row: two 16-byte stores
+//   - exp: 32-entry table of 2^(j/32) in LDS + degree-6 polynomial on |r| <= ln2/64
+//     (truncation 3.5e-18; measured <= 1 ulp), magic-number rounding, integer clamp, v_ldexp_f64
+//   - v / b_i is a reciprocal (hardware seed + two Newton steps); tiny, huge or zero b_i
+//     (exact power-of-two rescale; 0 when b_i == 0, TF:1773-1778) take a wave-uniform side path
 //   - K steps, mixture padding and "posteriors wanted" are compile-time
-//   - the epilogue is branch-free: lanes without an output store to a sink
-//   - v / b_i is a reciprocal (hardware seed + two Newton steps) after an exact
-//     power-of-two rescale of tiny or huge b_i; 0 when b_i == 0 (TF:1773-1778)
 constexpr int EMS_WAVES = 16;
+// Measurement builds only (profiles/tools/lab.sh compiles the library with -DGHMM_LAB=<bits> into
+// separate .so files; the product build leaves it 0): parts of k_emission_sched switched off so
+// that the rest can be timed on the hardware.  1: no exp, 2: no stores, 4: no MFMA chain,
+// 8: no state sums / reciprocal.
+#ifndef GHMM_LAB
+#define GHMM_LAB 0
+#endif
+#ifndef GHMM_EMS_W
+#define GHMM_EMS_W 12 // waves per block: 3 per SIMD, 168 registers each (measured against 16 and 8)
+#endif
+#ifndef GHMM_EMS_PF
+#define GHMM_EMS_PF 1 // next frame tile fetched into registers while the current one computes
+#endif
+// waves per block: 12 (3 per SIMD, 168 registers each) hold the x operands of a frame tile
+// (x', x'^2: 40 registers), the next frame tile on its way from HBM (20) and, where a state
+// spans 2 or 4 tiles, the densities of those tiles until the state's sum is known
+__host__ __device__ constexpr int ems_waves(int MP) { return MP >= 32 ? 12 : GHMM_EMS_W; }
 
-template <int MP> __device__ inline double segment_sum_t(double v)
-{
-    if (MP >= 2) v += dpp_f64<DPP_QUAD_XOR1>(v);
-    if (MP >= 4) v += dpp_f64<DPP_QUAD_XOR2>(v);
-    if (MP >= 8) v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
-    if (MP >= 16) v += dpp_f64<DPP_ROW_MIRROR>(v);
-    return v;
-}
+// 2^(j/32), j = 0..31, correctly rounded
+__device__ const double EXP2_32[32] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
 
-// exp_emis on four values at once: four independent dependency chains
-__device__ inline void exp_emis4(const v4d &x, double (&out)[4])
+// exp on four values at once (four independent chains): x = n ln2/32 + r, exp(x) =
+// 2^(n>>5) * 2^((n&31)/32) * exp(r).  `etab` = EXP2_32 in LDS.
+__device__ inline void exp_emis4(const v4d &x, const double *__restrict__ etab, double (&out)[4])
 {
-    double k[4], r[4], p[4];
+    double r[4], p[4];
     int ki[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -503,159 +541,259 @@ __device__ inline void exp_emis4(const v4d &x, double (&out)[4])
         const unsigned hi = (unsigned)__double2hiint(x[q]);
         const double xc = __hiloint2double((int)(hi < 0xC0877000u ? hi : 0xC0877000u), __double2loint(x[q]));
         // round to nearest by adding 1.5 * 2^52: the integer lands in the low mantissa bits
-        const double t = fma(xc, 1.4426950408889634074, 0x1.8p52);
+        const double t = fma(xc, 0x1.71547652b82fep+5, 0x1.8p52); // 32 / ln2
         ki[q] = __double2loint(t);
-        k[q] = t - 0x1.8p52;
-        r[q] = fma(-k[q], 6.93147180369123816490e-01, xc);
-        r[q] = fma(-k[q], 1.90821492927058770002e-10, r[q]);
-        p[q] = 2.08767569878680989792e-09; // 1/12!: |r| <= ln2/2, the next term is below 1.7e-16
+        const double k = t - 0x1.8p52;
+        r[q] = fma(-k, 0x1.62e42fee00000p-6, xc);  // ln2/32, high part (k * hi is exact)
+        r[q] = fma(-k, 0x1.a39ef35793c76p-38, r[q]);
+        p[q] = 1.38888888888888888889e-03; // 1/720
     }
-    const double cf[11] = {2.50521083854417187751e-08, 2.75573192239858906526e-07,
-                           2.75573192239858906526e-06, 2.48015873015873015873e-05,
-                           1.98412698412698412698e-04, 1.38888888888888888889e-03,
-                           8.33333333333333333333e-03, 4.16666666666666666667e-02,
-                           1.66666666666666666667e-01, 0.5,
-                           1.0};
+    const double cf[5] = {8.33333333333333333333e-03, 4.16666666666666666667e-02,
+                          1.66666666666666666667e-01, 0.5, 1.0};
 #pragma unroll
-    for (int t = 0; t < 11; t++)
+    for (int t = 0; t < 5; t++)
 #pragma unroll
         for (int q = 0; q < 4; q++) p[q] = fma(p[q], r[q], cf[t]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) out[q] = ldexp(fma(p[q], r[q], 1.0), ki[q]);
+    for (int q = 0; q < 4; q++) {
+        // (the table is read here, not ahead of the polynomial: four waves per SIMD cover the
+        // LDS latency, and the kernel sits at its 128-register limit)
+        const double tj = etab[ki[q] & 31];
+        out[q] = ldexp(fma(tj, p[q] * r[q], tj), ki[q] >> 5);
+    }
 }
 
-template <int MP> __device__ inline double segment_max_t(double v)
+// v_permlane16_swap / v_permlane32_swap with both operands the same value: the two results
+// are the value of the lane's partner half and its own, whichever way round — their sum
+// (max) is the sum (max) over the pair of 16-lane rows {0,1} / {2,3}, resp. over the two
+// halves of the wave, in every lane.
+__device__ inline void swap16_pair(double v, double &a, double &b)
 {
-    if (MP >= 2) v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
-    if (MP >= 4) v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
-    if (MP >= 8) v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
-    if (MP >= 16) v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    a = __hiloint2double((int)rh[0], (int)rl[0]);
+    b = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+__device__ inline void swap32_pair(double v, double &a, double &b)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __hiloint2double((int)rh[0], (int)rl[0]);
+    b = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+// sum / max over the lanes l>>4 = kq that share a state of MPL mixtures (slots 4kq .. 4kq+3)
+template <int MPL> __device__ inline double kq_sum(double v)
+{
+    double a, b;
+    if (MPL >= 8) {
+        swap16_pair(v, a, b);
+        v = a + b;
+    }
+    if (MPL >= 16) {
+        swap32_pair(v, a, b);
+        v = a + b;
+    }
+    return v;
+}
+template <int MPL> __device__ inline double kq_max(double v)
+{
+    double a, b;
+    if (MPL >= 8) {
+        swap16_pair(v, a, b);
+        v = fmax(a, b);
+    }
+    if (MPL >= 16) {
+        swap32_pair(v, a, b);
+        v = fmax(a, b);
+    }
     return v;
 }
 
-// State sums by a transposing butterfly: at the xor-1 and xor-2 levels each lane keeps only the
-// rows whose index matches its lane bits and sends the others, so that after the sums lane j holds
-// the sum of ONE row, r = j & 3 (MPL >= 4), or of two rows r = (j & 1) and 2 + (j & 1)
-// (MPL == 2).  The additions pair the same lanes as a plain butterfly: bit-identical sums.
-template <int MPL, int NV>
-__device__ inline void transposed_sums(const double (&tot)[4], int j, double (&sv)[NV])
+// 1 / s for the posteriors; 0 when s == 0 (TF:1773-1778).  Normal-range s: hardware seed + two
+// Newton steps (= the IEEE quotient's reciprocal in every case measured).  Tiny, huge, zero or
+// NaN s anywhere in the wave: the exact power-of-two rescale on a side path (wave-uniform branch).
+__device__ inline double recip_post(double s)
 {
-    if (MPL == 1) {
-#pragma unroll
-        for (int r = 0; r < NV; r++) sv[r] = tot[r % 4];
-    } else {
-        const bool o0 = (j & 1) != 0;
-        double k0 = o0 ? tot[1] : tot[0], k1 = o0 ? tot[3] : tot[2];
-        const double s0 = o0 ? tot[0] : tot[1], s1 = o0 ? tot[2] : tot[3];
-        k0 += dpp_f64<DPP_QUAD_XOR1>(s0);
-        k1 += dpp_f64<DPP_QUAD_XOR1>(s1);
-        if (MPL == 2) {
-            sv[0] = k0;
-            sv[NV - 1] = k1;
-        } else {
-            const bool o1 = (j & 2) != 0;
-            double kk = o1 ? k1 : k0;
-            const double ss = o1 ? k0 : k1;
-            kk += dpp_f64<DPP_QUAD_XOR2>(ss);
-            if (MPL >= 8) kk += dpp_xor4_f64(kk);
-            if (MPL >= 16) kk += dpp_f64<DPP_ROW_ROR8>(kk);
-            sv[0] = kk;
-        }
+    double rr = __builtin_amdgcn_rcp(s);
+    rr = fma(rr, fma(-s, rr, 1.0), rr);
+    rr = fma(rr, fma(-s, rr, 1.0), rr);
+    const bool odd = !(s >= 1.0e-290 && s <= 1.0e290);
+    if (__any(odd)) {
+        // (the empty asm keeps this a branch: folded into selects, the side path would cost every
+        // tile a second reciprocal and a dozen selects)
+        asm volatile("" ::: "memory");
+        const double sc = s < 1.0e-290 ? 0x1p600 : (s > 1.0e290 ? 0x1p-600 : 1.0);
+        const double s2 = s * sc;
+        double r2 = __builtin_amdgcn_rcp(s2);
+        r2 = fma(r2, fma(-s2, r2, 1.0), r2);
+        r2 = fma(r2, fma(-s2, r2, 1.0), r2);
+        rr = odd ? (s != 0.0 ? r2 * sc : 0.0) : rr;
     }
+    return rr;
+}
+
+// MFMA row <-> slot of a Gaussian inside its tile of 16: the four accumulator rows of a lane,
+// (l>>4) + 4r, carry slots 4(l>>4) + r
+__device__ __host__ inline int slot_row(int p) { return (p >> 2) + 4 * (p & 3); }
+
+// LDS bytes of k_emission_sched for a chunk of TC tiles
+__host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves)
+{
+    const int KS = DP / 2, XS = DP + 2;
+    return (size_t)TC * KS * 64 * 8 + (size_t)waves * 16 * XS * 8 + (size_t)DP * 8 +
+           (size_t)TC * 16 * 8 + (size_t)TC * DP * 8 + 32 * 8 + (size_t)TC * 16 * 4 + (size_t)TC * 4 * 2 + 64;
 }
 
 // OUT 0: b (recogniser, RF:860-889); 1: b and posteriors (trainer, TF:1749-1783);
 // 2: log b for the Viterbi lattice, m + log(sum exp(e - m)) like the oracle's definition
+// (wkp then holds log wk).  tfull[tile]: the tile's 16 slots are 16 consecutive real Gaussians
+// starting at an even index and G is even (its posteriors go out as aligned 16-byte stores).
 template <int KS, int MP, int OUT>
-__global__ void __launch_bounds__(EMS_WAVES *WAVE)
+__global__ void __launch_bounds__(ems_waves(MP) * WAVE)
 k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double *__restrict__ X,
                  const double *__restrict__ Wm, const double *__restrict__ oglob,
                  const double *__restrict__ wkp, const int *__restrict__ gmap,
-                 double *__restrict__ b, double *__restrict__ post, double *__restrict__ sink,
+                 double *__restrict__ b, double *__restrict__ post,
                  const int *__restrict__ anyflag, int epoch, const double *__restrict__ dtile,
-                 const int *__restrict__ tshift)
+                 const int *__restrict__ tshift, const int *__restrict__ tfull)
 {
     extern __shared__ double lds[];
     if (anyflag[0] == epoch) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
-    constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 1;
+    // slab row stride 2 * odd doubles: the 32 lanes of a ds_read_b64 group (16 frames x 2
+    // k-columns) then fall on 32 different bank pairs
+    constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 2, WV = ems_waves(MP);
     constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : MP == 16 ? 4 : MP == 32 ? 5 : 6;
     constexpr int MPL = MP < 16 ? MP : 16, TPS = MP <= 16 ? 1 : MP / 16;
+    constexpr int NS = MPL == 1 ? 4 : (MPL == 2 ? 2 : 1); // states per lane
+    constexpr int GS = 4 / NS;                            // a state's registers in the lane
     const int G = N * M;
-    double *Wl = lds;                                // [TC][KS][64]
-    double *xl = Wl + (size_t)TC * KS * 64;          // [EMS_WAVES][16][XS]
-    double *ol = xl + (size_t)EMS_WAVES * 16 * XS;   // [DP]
-    double *wkl = ol + DP;                           // [TC][16]
-    // output cursors per (tile, lane & 15): element offset {posterior, b} inside a frame row,
-    // or the distance to the lane's sink slot, and the row stride {G, N} or 0 for the sink
-    long long *offl = (long long *)(wkl + (size_t)TC * 16); // [TC][16][2]
-    unsigned *strl = (unsigned *)(offl + (size_t)TC * 32);  // [TC][16][2]
+    double *Wl = lds;                                // [TC][KS][64], Gaussians on their MFMA rows
+    double *xl = Wl + (size_t)TC * KS * 64;          // [WV][16][XS]
+    double *ol = xl + (size_t)WV * 16 * XS;   // [DP]
+    double *wkl = ol + DP;                           // [TC][16] by slot
     // tiles that hold a variance-floored component take that component's mean as their offset:
-    // dl = offset - oglob (subtracted from the A fragments of that tile), tsl = "shifted"
-    double *dl = (double *)(strl + (size_t)TC * 32);        // [TC][DP]
-    int *tsl = (int *)(dl + (size_t)TC * DP);               // [TC]
+    // dl = offset - oglob (subtracted from the x operand of that tile), tsl = "shifted"
+    double *dl = wkl + (size_t)TC * 16;              // [TC][DP]
+    double *etab = dl + (size_t)TC * DP;             // [32]
+    int *gml = (int *)(etab + 32);                   // [TC][16] real Gaussian of a slot, -1 = padding
+    int *tsl = gml + (size_t)TC * 16;                // [TC]
+    int *tfl = tsl + TC;                             // [TC] all 16 slots real, consecutive, even start
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index, in a scalar register
     const int c0 = blockIdx.y * TC;
     const int tc = (NT - c0) < TC ? (NT - c0) : TC;
-    for (int k = tid; k < tc * KS * 64; k += EMS_WAVES * WAVE) Wl[k] = Wm[(size_t)c0 * KS * 64 + k];
-    for (int k = tid; k < tc * 16; k += EMS_WAVES * WAVE) {
-        wkl[k] = wkp[c0 * 16 + k];
-        const int gm = gmap[c0 * 16 + k], jj = k & 15;
-        const int stt = (c0 * 16 + k) >> LOGMP;
-        const bool hold = (MPL >= 4 ? (jj & (MPL - 1)) < 4 : true) && stt < N;
-        // (sink slots of this block: its first wave's region)
-        double *bsink = sink + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * EMS_WAVES % SINK_WAVES) * 2 * WAVE;
-        offl[2 * k] = OUT != 1 ? 0 : (gm >= 0 ? (long long)gm : (bsink + jj) - post);
-        offl[2 * k + 1] = hold ? (long long)stt : (bsink + 16 + jj) - b;
-        strl[2 * k] = gm >= 0 ? (unsigned)G : 0u;
-        strl[2 * k + 1] = hold ? (unsigned)N : 0u;
-    }
-    for (int k = tid; k < DP; k += EMS_WAVES * WAVE) ol[k] = k < D ? oglob[k] : 0.0;
-    for (int k = tid; k < tc * DP; k += EMS_WAVES * WAVE) dl[k] = dtile[(size_t)c0 * DP + k];
-    for (int k = tid; k < tc; k += EMS_WAVES * WAVE) tsl[k] = tshift[c0 + k];
-    __syncthreads();
-    double *xw = xl + w * 16 * XS;
-    const long long ntf = (F + 15) / 16;
-    const long long FD = F * D;
-    // constant columns of the slab: the 1 at column D, zeros beyond
-    for (int k = l; k < 16 * (DP - D); k += WAVE) {
-        const int r = k / (DP - D), e = k - r * (DP - D);
-        xw[r * XS + D + e] = e == 0 ? 1.0 : 0.0;
-    }
-    const int q64 = 64 / D, r64 = 64 - q64 * D; // element index step 64 in (row, column) form
-    double *snk = wave_sink(sink);
-    const double *xr = xw + j * XS + kq; // A operand: frame l&15, k = 4s + (l>>4)
+    // this wave's share of the work units and its first frame tile: the load is issued before
+    // the block's tables are filled, so that its HBM latency runs under the set-up.
     // Work units = (frame tile, group of TPS Gaussian tiles), dealt to the grid's waves in
     // equal contiguous shares: with whole frame tiles per wave, 18 750 tiles on 4 096 waves
     // left 42 % of the CUs idle during the last of five rounds.  A wave that starts or ends
     // inside a frame tile loads that tile's slab like any other.
+    const long long ntf = (F + 15) / 16;
+    const long long FD = F * D;
+    const bool x16 = (((unsigned long long)X) & 15ull) == 0;
     const int ng = (tc + TPS - 1) / TPS;
-    const long long U = ntf * ng, GWV = (long long)gridDim.x * EMS_WAVES;
-    const long long gwv = (long long)blockIdx.x * EMS_WAVES + w;
+    const long long U = ntf * ng, GWV = (long long)gridDim.x * WV;
+    const long long gwv = (long long)blockIdx.x * WV + w;
     long long u = U * gwv / GWV;
     const long long u1 = U * (gwv + 1) / GWV;
     long long tf = u / ng;
     int g0 = (int)(u - tf * ng);
+    // 8 D pieces of 16 bytes per frame tile, lane l moves pieces l + 64u; surplus lanes repeat
+    // the last piece, load and store alike
+    constexpr int NP = (8 * (DP - 1) + 63) / 64; // D <= DP - 1
+    v2d xn[NP];
+    const int np = 8 * D;
+    auto loadx = [&](long long tfx) {
+        const v2d *src = (const v2d *)(X + uniform64(tfx * 16 * D));
+#pragma unroll
+        for (int u2 = 0; u2 < NP; u2++) {
+            int pc = l + 64 * u2;
+            pc = pc < np ? pc : np - 1;
+            xn[u2] = src[pc];
+        }
+    };
+    bool have = GHMM_EMS_PF && u < u1 && x16 && tf * 16 + 16 <= F; // xn holds the frames of tile tf (wave-uniform)
+    if (have) loadx(tf);
+    for (int k = tid; k < tc * KS * 64; k += WV * WAVE)
+        Wl[(k & ~15) | slot_row(k & 15)] = Wm[(size_t)c0 * KS * 64 + k];
+    for (int k = tid; k < tc * 16; k += WV * WAVE) {
+        wkl[k] = wkp[c0 * 16 + k];
+        gml[k] = gmap[c0 * 16 + k];
+    }
+    for (int k = tid; k < tc; k += WV * WAVE) {
+        tsl[k] = tshift[c0 + k];
+        tfl[k] = tfull[c0 + k];
+    }
+    for (int k = tid; k < DP; k += WV * WAVE) ol[k] = k < D ? oglob[k] : 0.0;
+    for (int k = tid; k < tc * DP; k += WV * WAVE) dl[k] = dtile[(size_t)c0 * DP + k];
+    if (tid < 32) etab[tid] = EXP2_32[tid];
+    __syncthreads();
+    // per-tile flags of the chunk as bit masks in scalar registers (TC <= 32): no LDS round trip
+    // per tile for them
+    unsigned shm = 0, fum = 0;
+    for (int k = 0; k < tc; k++) {
+        shm |= (tsl[k] != 0 ? 1u : 0u) << k;
+        fum |= (tfl[k] != 0 ? 1u : 0u) << k;
+    }
+    shm = (unsigned)__builtin_amdgcn_readfirstlane((int)shm);
+    fum = (unsigned)__builtin_amdgcn_readfirstlane((int)fum);
+    double *xw = xl + w * 16 * XS;
+    // constant columns of the slab: the 1 at column D, zeros beyond
+    for (int k = l; k < 16 * (XS - D); k += WAVE) {
+        const int r = k / (XS - D), e = k - r * (XS - D);
+        xw[r * XS + D + e] = e == 0 ? 1.0 : 0.0;
+    }
+    const double *xr = xw + j * XS + kq; // x operand: frame l&15, k = 4s + (l>>4)
+    if (GHMM_LAB & 32) return; // (lab: block set-up only)
     for (; u < u1; tf++, g0 = 0) {
         const long long f0 = tf * 16;
         const int g1 = (u1 - u) < (long long)(ng - g0) ? g0 + (int)(u1 - u) : ng;
         u += g1 - g0;
-        {
-            // the wave's 16 x D frame tile is contiguous in HBM; lane l moves elements
-            // l + 64u (clamped addresses, never predicated).  No register prefetch: with
-            // four waves per SIMD the other waves cover this latency.
-            const long long base = f0 * D + l;
-            double xn[EM_XR];
+        const bool full = f0 + 16 <= F; // wave-uniform
+        if (full && x16) {
+            // the wave's 16 x D frame tile is contiguous in HBM and starts on a 16-byte
+            // boundary (f0 is a multiple of 16)
+            if (!have) loadx(tf);
+            const int q128 = 128 / D, r128 = 128 - q128 * D; // element index step 128 in (row, column) form
+            int e0 = 2 * l, r = e0 / D, d = e0 - r * D;
 #pragma unroll
-            for (int u = 0; u < EM_XR; u++) {
-                long long q = base + 64 * u;
-                q = q < FD ? q : FD - 1;
-                xn[u] = X[q];
+            for (int u2 = 0; u2 < NP; u2++) {
+                if (u2 < NP - 1 || l + 64 * u2 < np) { // (only the last piece can be surplus: D >= DP - 4)
+                    const int d1 = d + 1 < D ? d + 1 : 0, r1 = d + 1 < D ? r : r + 1;
+                    xw[r * XS + d] = xn[u2][0] - ol[d];
+                    xw[r1 * XS + d1] = xn[u2][1] - ol[d1];
+                }
+                r += q128;
+                d += r128;
+                if (d >= D) {
+                    d -= D;
+                    r++;
+                }
             }
+            // the wave's next frame tile (if it has one and it is a whole tile) is fetched now,
+            // under this tile's matrix and vector work
+            have = GHMM_EMS_PF && u < u1 && f0 + 32 <= F;
+            if (have) loadx(tf + 1);
+        } else {
+            // ragged last tile of the corpus, or frames on an odd 8-byte boundary: 8 bytes per
+            // lane, addresses clamped into the corpus (never predicated)
+            constexpr int NL = (16 * (DP - 1) + 63) / 64;
+            const long long base = f0 * D + l;
+            double xs[NL];
+            have = false;
+#pragma unroll
+            for (int u2 = 0; u2 < NL; u2++) {
+                long long q = base + 64 * u2;
+                q = q < FD ? q : FD - 1;
+                xs[u2] = X[q];
+            }
+            const int q64 = 64 / D, r64 = 64 - q64 * D;
             int r = l / D, d = l - r * D;
 #pragma unroll
-            for (int u = 0; u < EM_XR; u++) {
-                if (l + 64 * u < 16 * D) xw[r * XS + d] = xn[u] - ol[d];
+            for (int u2 = 0; u2 < NL; u2++) {
+                if (u2 < NL - 1 || l + 64 * u2 < 16 * D) xw[r * XS + d] = xs[u2] - ol[d];
                 r += q64;
                 d += r64;
                 if (d >= D) {
@@ -665,10 +803,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
-        // the A fragments of this frame tile (x' and x'^2 of frame l & 15, k = 4s + (l >> 4))
+        // the x operands of this frame tile (x' and x'^2 of frame l & 15, k = 4s + (l >> 4))
         // stay in registers for all of its Gaussian tiles where the epilogue leaves room
         // (128 VGPRs = 4 waves per SIMD); otherwise they are re-read from the slab per tile
-        constexpr bool AREG = OUT != 2 && TPS == 1;
+        constexpr bool AREG = OUT != 2 || TPS > 1;
         double a1[AREG ? Q : 1], a2[AREG ? Q : 1];
         if (AREG) {
 #pragma unroll
@@ -677,163 +815,156 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 a2[s] = a1[s] * a1[s];
             }
         }
-        // a state's mixtures fill MPL adjacent lanes of TPS consecutive tiles
+        const long long fr = f0 + j;   // this lane's frame
+        const bool fok = full || fr < F;
+        if (GHMM_LAB & 64) { // (lab: frame tiles only)
+            if (a1[0] + a2[AREG ? Q - 1 : 0] == 12345.678) b[fr] = a1[0];
+            continue;
+        }
+        // a state's mixtures fill MPL adjacent slots of TPS consecutive tiles
+        double zero = 0.0; // (opaque to the compiler below: orders the tiles of a multi-tile state)
         for (int ct = g0 * TPS; ct < g1 * TPS; ct += TPS) {
             double e[TPS][4];
 #pragma unroll
             for (int tt = 0; tt < TPS; tt++) {
-                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                v4d acc = {zero, zero, zero, zero};
                 const double *Wt = Wl + (size_t)(ct + tt) * KS * 64 + l;
-                if (__builtin_amdgcn_readfirstlane(tsl[ct + tt]) != 0) {
+                if ((shm >> (ct + tt)) & 1u) {
                     // this tile's own offset: x'' = x' - (offset - oglob), from the slab
                     const double *dq = dl + (ct + tt) * DP + kq;
 #pragma unroll 5
                     for (int s = 0; s < Q; s++) {
                         const double x1 = xr[4 * s] - dq[4 * s];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, Wt[s * 64], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1 * x1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[s * 64], x1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(Q + s) * 64], x1 * x1, acc, 0, 0, 0);
                     }
+                } else if (AREG && (GHMM_LAB & 4)) {
+                    const double w0 = Wt[0];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[r] = -fabs(w0 * a1[AREG ? r : 0]);
                 } else if (AREG) {
 #pragma unroll
                     for (int s = 0; s < Q; s++) {
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[AREG ? s : 0], Wt[s * 64], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[AREG ? s : 0], Wt[(Q + s) * 64], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[s * 64], a1[AREG ? s : 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(Q + s) * 64], a2[AREG ? s : 0], acc, 0, 0, 0);
                     }
                 } else {
 #pragma unroll 5
                     for (int s = 0; s < Q; s++) {
                         const double x1 = xr[4 * s];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, Wt[s * 64], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x1 * x1, Wt[(Q + s) * 64], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[s * 64], x1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(Q + s) * 64], x1 * x1, acc, 0, 0, 0);
                     }
                 }
-                const double wkj = wkl[(ct + tt) * 16 + j];
+                // acc[r]: exponent of slot 4 kq + r at frame l & 15
                 if (OUT == 2) {
                     // wkl holds log(wk) here: keep the exponents, exponentiate after the max
+                    const v4d wk4 = *(const v4d *)(wkl + (ct + tt) * 16 + 4 * kq);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) e[tt][r] = acc[r] + wkj;
+                    for (int r = 0; r < 4; r++) e[tt][r] = acc[r] + wk4[r];
                 } else {
-                    exp_emis4(acc, e[tt]);
+                    if (GHMM_LAB & 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) e[tt][r] *= wkj;
+                        for (int r = 0; r < 4; r++) e[tt][r] = acc[r];
+                    } else {
+                        exp_emis4(acc, etab, e[tt]);
+                    }
+                    const v4d wk4 = *(const v4d *)(wkl + (ct + tt) * 16 + 4 * kq);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) e[tt][r] *= wk4[r];
                 }
+                // a state that spans several tiles: one tile at a time — left alone, the compiler runs
+                // the MFMA chains of all of them first and then their exponentials side by side,
+                // which takes more registers than there are.  The empty asm ties the next tile's
+                // accumulator start to this tile's finished densities.
+                if (TPS > 1)
+                    asm volatile("" : "+v"(e[tt][0]), "+v"(e[tt][1]), "+v"(e[tt][2]), "+v"(e[tt][3]), "+v"(zero));
             }
+            // first state of this lane and whether the lane stores it (one lane per state)
+            const int st0 = ((c0 + ct) * 16 + 4 * kq) >> LOGMP;
+            const bool holder = MPL <= 4 || (kq & (MPL / 4 - 1)) == 0;
             if (OUT == 2) {
-                double mx[4];
+                // log b_i = m + log(sum exp(e - m)), m = the state's largest exponent
+                double m[NS], sm[NS], lb[NS];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    double m = e[0][r];
+                for (int v = 0; v < NS; v++) {
+                    double t = e[0][v * GS];
 #pragma unroll
-                    for (int tt = 1; tt < TPS; tt++) m = fmax(m, e[tt][r]);
-                    mx[r] = segment_max_t<MPL>(m);
+                    for (int tt = 0; tt < TPS; tt++)
+#pragma unroll
+                        for (int r = 0; r < GS; r++) t = fmax(t, e[tt][v * GS + r]);
+                    m[v] = kq_max<MPL>(t);
+                    sm[v] = 0.0;
                 }
-                v4d sum4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int tt = 0; tt < TPS; tt++) {
                     v4d dlt;
                     double ex[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) dlt[r] = e[tt][r] - mx[r];
-                    exp_emis4(dlt, ex);
+                    for (int r = 0; r < 4; r++) dlt[r] = e[tt][r] - m[r / GS];
+                    exp_emis4(dlt, etab, ex);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) sum4[r] += ex[r];
+                    for (int r = 0; r < 4; r++) sm[r / GS] += ex[r];
                 }
-                // sum over the state's lanes transposed: one (frame, state) and one log per lane
-                constexpr int NV2 = MPL >= 4 ? 1 : (MPL == 2 ? 2 : 4);
-                double s4[4] = {sum4[0], sum4[1], sum4[2], sum4[3]}, sv2[NV2];
-                transposed_sums<MPL, NV2>(s4, j, sv2);
-                const long long boff2 = offl[2 * (ct * 16 + j) + 1];
-                const unsigned bstr2 = strl[2 * (ct * 16 + j) + 1];
 #pragma unroll
-                for (int v = 0; v < NV2; v++) {
-                    const int rw = MPL >= 4 ? (j & 3) : (MPL == 2 ? 2 * v + (j & 1) : v);
-                    double mxr;
-                    if (MPL >= 4) mxr = (j & 2) ? ((j & 1) ? mx[3] : mx[2]) : ((j & 1) ? mx[1] : mx[0]);
-                    else if (MPL == 2) mxr = (j & 1) ? mx[(2 * v + 1) % 4] : mx[(2 * v) % 4];
-                    else mxr = mx[v % 4];
-                    const double lb = mxr < -1.0e299 ? -INFINITY : mxr + log(sv2[v]);
-                    double *pb = b + ((unsigned long long)((unsigned)(f0 + kq) + 4 * rw) * bstr2 + boff2);
-                    pb = f0 + kq + 4 * rw < F ? pb : snk;
-                    *pb = lb;
+                for (int v = 0; v < NS; v++) {
+                    const double st = kq_sum<MPL>(sm[v]);
+                    lb[v] = m[v] < -1.0e299 ? -INFINITY : m[v] + log(st);
+                }
+                if (fok && holder) {
+#pragma unroll
+                    for (int v = 0; v < NS; v++)
+                        if (st0 + v < N) b[fr * N + st0 + v] = lb[v];
                 }
                 continue;
             }
-            // state sums, transposed: one (frame, state) per lane (transposed_sums above).  The
-            // reciprocal for the posteriors (TF:1773-1778) is then formed once per (frame, state)
-            // instead of once per lane and row, and handed back to the state's lanes by quad
-            // broadcasts.
-            constexpr int NV = MPL >= 4 ? 1 : (MPL == 2 ? 2 : 4);
-            double sv[NV];
-            {
-                double tot[4];
+            // state sums in the lane, then across the kq lanes of the state
+            double sm[NS];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    tot[r] = e[0][r];
-#pragma unroll
-                    for (int tt = 1; tt < TPS; tt++) tot[r] += e[tt][r];
-                }
-                transposed_sums<MPL, NV>(tot, j, sv);
-            }
-            // rows held by this lane: rw = v-th held row; b is stored by the first lanes of the
-            // state's group (one per row), everything else goes to the sink (cursor tables)
-            const unsigned frow = (unsigned)(f0 + kq);
-            const bool full = f0 + 16 <= F; // wave-uniform
-            const long long boff = offl[2 * (ct * 16 + j) + 1];
-            const unsigned bstr = strl[2 * (ct * 16 + j) + 1];
-            double rrv[NV];
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                const int rw = MPL >= 4 ? (j & 3) : (MPL == 2 ? 2 * v + (j & 1) : v);
-                double *pb = b + ((unsigned long long)(frow + 4 * rw) * bstr + boff);
-                if (!full) pb = (long long)frow + 4 * rw < F ? pb : snk;
-                const double sm = sv[v];
-                *pb = sm;
-                if (OUT == 1) {
-                    // gauss[i][j] /= b_i, 0 when b_i == 0: reciprocal (hardware seed + two
-                    // Newton steps = the IEEE quotient in every case measured) after an exact
-                    // power-of-two rescale of a tiny or huge b_i
-                    const double sc = sm < 1.0e-290 ? 0x1p600 : (sm > 1.0e290 ? 0x1p-600 : 1.0);
-                    const double s2 = sm * sc;
-                    double rr = __builtin_amdgcn_rcp(s2);
-                    rr = fma(rr, fma(-s2, rr, 1.0), rr);
-                    rr = fma(rr, fma(-s2, rr, 1.0), rr);
-                    rrv[v] = sm != 0.0 ? rr * sc : 0.0;
-                }
-            }
-            if (OUT == 1) {
-                double rr4[4];
-                if (MPL >= 4) {
-                    rr4[0] = dpp_f64<0x00>(rrv[0]); // quad_perm:[r,r,r,r]
-                    rr4[1] = dpp_f64<0x55>(rrv[0]);
-                    rr4[2] = dpp_f64<0xAA>(rrv[0]);
-                    rr4[3] = dpp_f64<0xFF>(rrv[0]);
-                } else if (MPL == 2) {
-                    rr4[0] = dpp_f64<0xA0>(rrv[0]);      // quad_perm:[0,0,2,2]: the pair's even lane
-                    rr4[1] = dpp_f64<0xF5>(rrv[0]);      // quad_perm:[1,1,3,3]: the pair's odd lane
-                    rr4[2] = dpp_f64<0xA0>(rrv[NV - 1]);
-                    rr4[3] = dpp_f64<0xF5>(rrv[NV - 1]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) rr4[r] = rrv[r % NV];
-                }
-                // posterior cursor of this lane for row 0 (frame f0 + kq), 4 frames per r; a
-                // lane without an output has cursor = sink and stride 0, rows past the end of
-                // a ragged last tile go to the sink too: branches around the stores were
-                // measured slower than these selects
+            for (int v = 0; v < NS; v++) {
+                double t = 0.0;
 #pragma unroll
                 for (int tt = 0; tt < TPS; tt++) {
-                    const long long goff = offl[2 * ((ct + tt) * 16 + j)];
-                    const unsigned gstr = strl[2 * ((ct + tt) * 16 + j)];
-                    double *pp0 = post + ((unsigned long long)frow * gstr + goff);
-                    const unsigned long long stp = (unsigned long long)(4u * gstr);
-                    if (full) {
+                    if (GS == 4) t += (e[tt][0] + e[tt][1]) + (e[tt][2] + e[tt][3]);
+                    else if (GS == 2) t += e[tt][2 * v] + e[tt][2 * v + 1];
+                    else t += e[tt][v];
+                }
+                sm[v] = (GHMM_LAB & 8) ? e[0][v] : kq_sum<MPL>(t);
+            }
+            if (fok && holder && !((GHMM_LAB & 2) && sm[0] != 12345.678)) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) pp0[r * stp] = e[tt][r] * rr4[r];
+                for (int v = 0; v < NS; v++)
+                    if (st0 + v < N) b[fr * N + st0 + v] = sm[v];
+            }
+            if (OUT == 1) {
+                // gauss[i][j] /= b_i, 0 when b_i == 0 (TF:1773-1778)
+                double rr[NS];
+#pragma unroll
+                for (int v = 0; v < NS; v++) rr[v] = (GHMM_LAB & 8) ? sm[v] : recip_post(sm[v]);
+#pragma unroll
+                for (int tt = 0; tt < TPS; tt++) {
+                    double pv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) pv[r] = e[tt][r] * rr[r / GS];
+                    if ((fum >> (ct + tt)) & 1u) {
+                        // the lane's four posteriors are 32 contiguous, 16-byte aligned bytes
+                        if (fok && !((GHMM_LAB & 2) && pv[0] + pv[1] + pv[2] + pv[3] != 12345.678)) {
+                            if (GHMM_LAB & 16) {
+                                // (lab: the same bytes as whole 128-byte lines, data misplaced)
+                                double *pp = post + ((f0 + (l >> 3)) * G + gml[(ct + tt) * 16] + 2 * (l & 7));
+                                *(v2d *)pp = (v2d){pv[0], pv[1]};
+                                *(v2d *)(pp + 8 * G) = (v2d){pv[2], pv[3]};
+                            } else {
+                            double *pp = post + (fr * G + gml[(ct + tt) * 16 + 4 * kq]);
+                            *(v2d *)pp = (v2d){pv[0], pv[1]};
+                            *(v2d *)(pp + 2) = (v2d){pv[2], pv[3]};
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            double *pp = (long long)frow + 4 * r < F ? pp0 + r * stp : snk;
-                            *pp = e[tt][r] * rr4[r];
+                            const int gm = gml[(ct + tt) * 16 + 4 * kq + r];
+                            if (fok && gm >= 0) post[fr * G + gm] = pv[r];
                         }
                     }
                 }
@@ -853,14 +984,6 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
 // LDS (STAGED) or come straight from HBM/L2, prefetched a few k-steps ahead.  The four waves
 // of a block fold their tiles through LDS in wave order and the block writes ONE partial;
 // k_reduce_all adds the partials in a fixed order (bitwise reproducible).
-// a 64-bit value that is the same in every lane, moved to scalar registers
-__device__ inline long long uniform64(long long v)
-{
-    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
-    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-    return ((long long)hi << 32) | (unsigned)lo;
-}
-
 // e / d and e % d for small non-negative e (< 2^20) without the ~40-instruction integer
 // division: float reciprocal, then one correction either way
 __device__ inline void divmod_small(int e, int d, float rd, int &q, int &r)
@@ -879,8 +1002,6 @@ __device__ inline void divmod_small(int e, int d, float rd, int &q, int &r)
 
 constexpr int MSM_WAVES = 4;
 constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
-
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 // STAGED = true: frames go HBM -> registers -> LDS in 16-frame stages with fully
 // coalesced 16-byte-per-lane loads (one stage ahead), MFMA operands come from LDS.

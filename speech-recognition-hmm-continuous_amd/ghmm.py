@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, "libghmm_hip.so")
+# GHMM_HIP_LIB: a measurement build of the library (profiles/tools/lab.sh); default = the product
+HIP_LIB = os.environ.get("GHMM_HIP_LIB") or os.path.join(_HERE, "libghmm_hip.so")
 HOST_LIB = os.path.join(_HERE, "libghmm_host.so")
 
 OK = 0
