@@ -110,6 +110,7 @@ struct ghmm_model {
     // relative to the tile's offset; sflag: like anyflag, for the statistics (global offset)
     double *otile = nullptr, *dtile = nullptr, *condt = nullptr;
     int *tshift = nullptr, *sflag = nullptr, *tnext = nullptr; // tnext: the choice for the next preparation
+    int *scls = nullptr;  // [NT*16] how each padded Gaussian's statistics are taken (stats_class)
     int *tfull = nullptr; // [NT] the tile's slots are 16 consecutive real Gaussians, even start, G even
     bool banded = false; // A as last set from the host has a_ij = 0 unless j = i or i + 1
     int epoch = 0; // preparation count; anyflag[0] == epoch: this model holds an ill-conditioned Gaussian
@@ -456,7 +457,7 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
                            m->wk, m->logwk, m->otile, m->tnext, m->oglob, m->Wm, m->wkp, m->logwkp,
                            m->gmap, m->condt, m->condg, m->anyflag, m->sflag, m->epoch, m->dtile,
-                           m->tshift);
+                           m->tshift, m->scls);
     }
     return launch_ok("k_prepare_mfma");
 }
@@ -508,7 +509,7 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
                 (rc = dev_alloc(&m->otile, (size_t)m->NT * m->DP)) || (rc = dev_alloc(&m->dtile, (size_t)m->NT * m->DP)) ||
                 (rc = dev_alloc(&m->condt, (size_t)m->NT * 16)) || (rc = dev_alloc(&m->tshift, (size_t)m->NT)) ||
                 (rc = dev_alloc(&m->sflag, 1)) || (rc = dev_alloc(&m->tnext, (size_t)m->NT)) ||
-                (rc = dev_alloc(&m->tfull, (size_t)m->NT))) {
+                (rc = dev_alloc(&m->tfull, (size_t)m->NT)) || (rc = dev_alloc(&m->scls, (size_t)m->NT * 16))) {
                 ghmm_model_destroy(ctx, m);
                 return rc;
             }
@@ -520,6 +521,7 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
             if (e == hipSuccess) e = hipMemsetAsync(m->sflag, 0, sizeof(int), ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(m->anyflag, 0, sizeof(int), ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(m->tnext, 0, (size_t)m->NT * sizeof(int), ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(m->scls, 0, (size_t)m->NT * 16 * sizeof(int), ctx->stream);
             // which tiles hold 16 consecutive real Gaussians (a property of N, M and the padding)
             std::vector<int> tf((size_t)m->NT, 0);
             for (int t = 0; t < m->NT; t++) {
@@ -556,7 +558,7 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
     }
     void *bufs[] = {m->A,  m->c,    m->mean, m->inv_var, m->det,   m->wk,    m->logwk, m->logA,
                     m->Wm, m->offs, m->wkp,  m->condp,   m->gmap,  m->oglob, m->condg, m->anyflag,
-                    m->logwkp, m->otile, m->dtile, m->condt, m->tshift, m->sflag, m->tnext, m->tfull};
+                    m->logwkp, m->otile, m->dtile, m->condt, m->tshift, m->sflag, m->tnext, m->tfull, m->scls};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete m;
@@ -864,9 +866,11 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
     double *post = want_post ? ctx->post : nullptr;
     const bool sched_ok = m->mfma_ok && ctx->kernels != 1 &&
                           (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
-    if (mode == 2 && sched_ok) {
-        // log b for the Viterbi lattice on the matrix-core kernel; with an ill-conditioned
-        // Gaussian in the model it returns at once and the vector-ALU kernel below runs
+    if ((mode == 2 || mode == 0) && sched_ok) {
+        // The scheduled matrix-core kernel: compile-time K steps (D = 36..39 -> KS = 20) and
+        // mixture padding.  It needs no fallback launch: a Gaussian that is ill-conditioned even
+        // around its tile's offset is re-evaluated in direct form inside the kernel, for the few
+        // frames where its density is not 0.
         int rc;
         const long long ntf = (c->F + 15) / 16;
         const int chunks = (m->NT + m->TC - 1) / m->TC;
@@ -874,77 +878,55 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const size_t lds_s = ems_lds_bytes(m->TC, m->DP, wv);
         long long gxs = (ntf + wv - 1) / wv;
         if (gxs > ctx->cus) gxs = ctx->cus;
+        const int po = mode == 2 ? 2 : (post ? 1 : 0);
+        const double *wk = mode == 2 ? m->logwkp : m->wkp; // OUT = 2 adds log wk to the exponents
         kscope ks(ctx, GHMM_K_EMISSION);
-#define GHMM_EML(MP, IDX)                                                                         \
+#define GHMM_EMS(MP, PO)                                                                          \
     do {                                                                                          \
-        if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, 2>))) return rc;          \
-        hipLaunchKernelGGL((k_emission_sched<20, MP, 2>), dim3((unsigned)gxs, (unsigned)chunks), \
+        if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, PO>))) return rc;         \
+        hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3((unsigned)(wv * WAVE)), lds_s, ctx->stream, m->N, m->M, m->D, m->NT, \
-                           m->TC, c->F, c->X, m->Wm, m->oglob, m->logwkp, m->gmap, ctx->b,       \
-                           (double *)nullptr, m->anyflag, m->epoch, m->dtile, m->tshift, m->tfull); \
+                           m->TC, c->F, c->X, m->Wm, m->oglob, wk, m->gmap, ctx->b, post, m->dtile, \
+                           m->tshift, m->tfull, m->condt, m->mean, m->inv_var);                   \
+    } while (0)
+#define GHMM_EMS3(MP)                                                                             \
+    do {                                                                                          \
+        if (po == 2) GHMM_EMS(MP, 2);                                                             \
+        else if (po == 1) GHMM_EMS(MP, 1);                                                        \
+        else GHMM_EMS(MP, 0);                                                                     \
     } while (0)
         switch (m->Mp) {
-        case 1: GHMM_EML(1, 0); break;
-        case 2: GHMM_EML(2, 1); break;
-        case 4: GHMM_EML(4, 2); break;
-        case 8: GHMM_EML(8, 3); break;
-        case 16: GHMM_EML(16, 4); break;
-        case 32: GHMM_EML(32, 5); break;
-        default: GHMM_EML(64, 6); break;
+        case 1: GHMM_EMS3(1); break;
+        case 2: GHMM_EMS3(2); break;
+        case 4: GHMM_EMS3(4); break;
+        case 8: GHMM_EMS3(8); break;
+        case 16: GHMM_EMS3(16); break;
+        case 32: GHMM_EMS3(32); break;
+        default: GHMM_EMS3(64); break;
         }
+        ctx->b_is_log = (mode == 2);
+        return launch_ok("k_emission_sched");
     }
     if (mode == 0 && m->mfma_ok && ctx->kernels != 1) {
+        // other coefficient counts: the generic matrix-core kernel (direct-form tiles inside)
         int rc;
         if ((rc = lds_attr(ctx, (const void *)k_emission_mfma))) return rc;
         const long long ntf = (c->F + 15) / 16;
         const int chunks = (m->NT + m->TC - 1) / m->TC;
         long long gx = (ntf + EM_WAVES - 1) / EM_WAVES;
         if (gx > ctx->cus) gx = ctx->cus; // one 8-wave block per CU, chunks in grid.y
-        // scheduled variant: compile-time K steps (D = 39 -> KS = 20) and mixture padding,
-        // Mp <= 16.  It returns at once when the model holds an ill-conditioned Gaussian
-        // (anyflag, set on the device by k_prepare_mfma); the generic kernel launched right
-        // after it returns at once when it does not — no host round trip either way.
-        const bool sched = (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
-        const int wv = ems_waves(m->Mp);
-        const size_t lds_s = ems_lds_bytes(m->TC, m->DP, wv);
-        long long gxs = (ntf + wv - 1) / wv;
-        if (gxs > ctx->cus) gxs = ctx->cus;
         {
             kscope ks(ctx, GHMM_K_EMISSION);
-            if (sched) {
-#define GHMM_EMS(MP, PO)                                                                          \
-    do {                                                                                          \
-        if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, PO>))) return rc;         \
-        hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
-                           dim3((unsigned)(wv * WAVE)), lds_s, ctx->stream, m->N, m->M, m->D, m->NT, \
-                           m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap, ctx->b, post,     \
-                           m->anyflag, m->epoch, m->dtile, m->tshift, m->tfull);                  \
-    } while (0)
-#define GHMM_EMS2(MP)                                                                             \
-    do {                                                                                          \
-        if (post) GHMM_EMS(MP, 1);                                                                \
-        else GHMM_EMS(MP, 0);                                                                     \
-    } while (0)
-                switch (m->Mp) {
-                case 1: GHMM_EMS2(1); break;
-                case 2: GHMM_EMS2(2); break;
-                case 4: GHMM_EMS2(4); break;
-                case 8: GHMM_EMS2(8); break;
-                case 16: GHMM_EMS2(16); break;
-                case 32: GHMM_EMS2(32); break;
-                default: GHMM_EMS2(64); break;
-                }
-            }
             hipLaunchKernelGGL(k_emission_mfma, dim3((unsigned)gx, (unsigned)chunks),
                                dim3(EM_WAVES * WAVE), m->em_lds, ctx->stream, m->N, m->M, m->Mp, m->D,
                                m->DP, m->NT, m->TC, c->F, c->X, m->Wm, m->oglob, m->wkp, m->gmap,
-                               m->condt, m->mean, m->inv_var, ctx->b, post,
-                               sched ? m->anyflag : (const int *)nullptr, m->epoch, m->tshift, m->dtile);
+                               m->condt, m->mean, m->inv_var, ctx->b, post, (const int *)nullptr,
+                               m->epoch, m->tshift, m->dtile);
         }
         ctx->b_is_log = false;
         return launch_ok("k_emission_mfma");
     }
-    const int *only_if = (mode == 2 && sched_ok) ? m->anyflag : (const int *)nullptr;
+    const int *only_if = nullptr;
     {
         kscope ks(ctx, GHMM_K_EMISSION);
         if (mode == 0)
@@ -1229,7 +1211,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         hipLaunchKernelGGL(k_mixstats, dim3((unsigned)P, (unsigned)NB), dim3(MS_THREADS), lds,
                            ctx->stream, N, M, D, c->F, fpb, FS, c->X, ctx->gamma, ctx->post, m->mean,
                            ctx->part_mu, ctx->part_var, only_if, m->epoch,
-                           (mfma && G <= MS_MAXG) ? m->condg : (const double *)nullptr, m->Mp, COND_MAX);
+                           (mfma && G <= MS_MAXG) ? m->scls : (const int *)nullptr, m->Mp);
         if ((rc = launch_ok("k_mixstats"))) return rc;
     }
     {
@@ -1245,6 +1227,11 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         ra.gmap = m->gmap; ra.cond_max = COND_MAX;
         ra.otile = ra.Pm > 0 ? m->otile : nullptr;
         ra.tnext = m->tnext;
+        ra.scls = m->scls;
+        ra.X = c->X; ra.gamma = ctx->gamma; ra.post = ctx->post; ra.F = c->F;
+        // rounding bound of a sum of `len` terms accumulated in sequence (a wave's share of the
+        // frames) and then over the partials: (len + partials) * eps, doubled
+        ra.kappa = 2.0 * 1.1102230246251565e-16 * ((double)c->F / (double)(ctx->cus * MSM_WAVES) + 2.0 * ctx->cus + 64.0);
         ra.part_xi = ctx->part_xi; ra.part_dena = ctx->part_dena; ra.part_denc = ctx->part_denc;
         ra.loglik = ctx->loglik; ra.stats = s->v;
         if (mfma && c->F == 0) ra.P1 = 0; // nothing accumulated: every sum is empty
@@ -1372,7 +1359,7 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
                                pow(2.0 * M_PI, m->D / 2.0), m->A, m->c, m->mean, m->inv_var, m->det, m->wk,
                                m->logwk, m->logA, lds_doubles, m->Mp, m->NT, m->DP, m->oglob, m->Wm, m->wkp,
                                m->logwkp, m->gmap, m->condg, m->anyflag, m->epoch, m->otile, m->tnext,
-                               m->condt, m->dtile, m->tshift, m->sflag, (int)ctx->delta);
+                               m->condt, m->dtile, m->tshift, m->sflag, (int)ctx->delta, m->scls);
             return launch_ok("k_mstep_mfma");
         }
         hipLaunchKernelGGL(k_mstep, dim3((unsigned)m->N), dim3(MS2_THREADS), (size_t)lds_doubles * 8,

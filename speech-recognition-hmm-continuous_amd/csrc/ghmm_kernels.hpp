@@ -735,11 +735,11 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
            const double *__restrict__ X, const double *__restrict__ gamma,
            const double *__restrict__ post, const double *__restrict__ mean,
            double *__restrict__ part_mu, double *__restrict__ part_var,
-           const int *__restrict__ only_if, int epoch, const double *__restrict__ condg = nullptr,
-           int Mp = 0, double cond_max = 0.0)
+           const int *__restrict__ only_if, int epoch, const int *__restrict__ scls = nullptr,
+           int Mp = 0)
 {
     extern __shared__ double lds[];
-    __shared__ int fl[MS_MAXG]; // condg != nullptr: the ill-conditioned Gaussians, in index order
+    __shared__ int fl[MS_MAXG]; // scls != nullptr: the Gaussians of class 2 (ghmm_mfma.hpp), in index order
     __shared__ int nfl;
     if (only_if && only_if[0] != epoch) return; // matrix-core tier: nothing is ill-conditioned
     const int G = N * M, D1 = D + 1;
@@ -748,11 +748,11 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
     // (k_reduce_all): the element space shrinks to those Gaussians (a handful of variance-
     // floored components in a typical training run), every block builds the same list.
     int GE = G;
-    if (condg) {
+    if (scls) {
         if (tid == 0) {
             int n = 0;
             for (int g = 0; g < G; g++)
-                if (condg[(g / M) * Mp + g % M] > cond_max) fl[n++] = g;
+                if (scls[(g / M) * Mp + g % M] == 2) fl[n++] = g;
             nfl = n;
         }
         __syncthreads();
@@ -763,11 +763,11 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
     if (e0 >= EE) return;
     const long long e1 = (e0 + MS_THREADS * MS_EPT < EE) ? e0 + MS_THREADS * MS_EPT : EE;
     const int g0 = (int)(e0 / D1);
-    const int g1 = (int)((e1 - 1) / D1); // inclusive (compact indices when condg)
+    const int g1 = (int)((e1 - 1) / D1); // inclusive (compact indices behind the matrix-core kernel)
     const int GW = g1 - g0 + 1;
     double *xs = lds;                // [FS][D1]
     double *ws = lds + FS * D1;      // [FS][GW]
-    auto real = [&](int gc) { return condg ? fl[gc] : gc; };
+    auto real = [&](int gc) { return scls ? fl[gc] : gc; };
     const int kmax = (int)((e1 - e0 + MS_THREADS - 1) / MS_THREADS); // element slots in use per thread
 
     int gx[MS_EPT], dx[MS_EPT];
@@ -869,6 +869,12 @@ struct reduce_args {
     // the model the statistics were taken with; nullptr: tier not in use
     double *otile;
     int *tnext;
+    // statistics class per padded Gaussian (ghmm_mfma.hpp stats_class) and what the exact
+    // recomputation of a class-1 Gaussian that fails its check reads
+    const int *scls;
+    const double *X, *gamma, *post;
+    long long F;
+    double kappa; // relative rounding bound of the expanded sums (accumulation length x eps)
     double *stats;
 };
 
@@ -887,7 +893,8 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         if (g < 0) return;
         constexpr int SL = RD_THREADS / 128;
         const int e = tid & 127, half = tid >> 7;
-        if (a.Pm > 0 && !(a.condg[gp] > a.cond_max)) {
+        const int cls = a.Pm > 0 ? a.scls[gp] : 2;
+        if (cls != 2) {
             // four independent chains (fixed assignment of partials to chains: reproducible),
             // so that the loads of a thread overlap
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
@@ -911,14 +918,73 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
                 sh[tid] = t;
             }
             __syncthreads();
+            bool bad = false; // class 1: this coefficient's variance statistic is neither accurate
+                              // nor certain to end under the floor
             if (tid < D1) {
                 const double S0 = sh[D];
                 if (tid == D) {
                     num_c[g] = S0;
                 } else {
                     const double o = a.oglob[tid], mu = a.mean[(size_t)g * D + tid] - o;
-                    num_mu[(size_t)g * D + tid] = sh[tid] + o * S0;
-                    num_var[(size_t)g * D + tid] = (sh[a.DP + tid] - 2.0 * mu * sh[tid]) + mu * mu * S0;
+                    const double S1 = sh[tid], S2 = sh[a.DP + tid];
+                    const double V = (S2 - 2.0 * mu * S1) + mu * mu * S0;
+                    num_mu[(size_t)g * D + tid] = S1 + o * S0;
+                    num_var[(size_t)g * D + tid] = V;
+                    if (cls == 1) {
+                        // what cancelled, times the rounding bound of sums this long
+                        const double E = a.kappa * (fabs(S2) + 2.0 * fabs(mu * S1) + mu * mu * fabs(S0));
+                        const bool accurate = E <= 1.0e-9 * fabs(V);
+                        const bool floored = V + E < FLOOR * S0 * (1.0 - 1.0e-9); // M-step: max(V / S0, 1e-5)
+                        bad = !(accurate || floored);
+                    }
+                }
+            }
+            if (cls == 1 && __syncthreads_or(bad ? 1 : 0)) {
+                // A collapsed component whose variance statistic has come up to the floor: the
+                // reference's direct form over every frame, by this block alone (rare, ~0.1 ms).
+                // Lane = frame for the weights (64 frames per wave step, waves interleaved), then
+                // lane = coefficient for every frame that carries weight; fixed order throughout.
+                const int st = g / M, w = tid >> 6, l = tid & 63, NW = RD_THREADS / 64;
+                const double mu = l < D ? a.mean[(size_t)g * D + l] : 0.0;
+                double am = 0.0, av = 0.0, ac = 0.0;
+                for (long long t0 = (long long)w * 64; t0 < a.F; t0 += (long long)NW * 64) {
+                    const long long t = t0 + l;
+                    const double wt = t < a.F ? a.gamma[t * N + st] * a.post[t * G + g] : 0.0;
+                    unsigned long long m = __ballot(wt != 0.0);
+                    while (m) {
+                        const int k = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const double wk = __shfl(wt, k, 64);
+                        const double x = l < D ? a.X[(t0 + k) * D + l] : 0.0;
+                        const double dif = x - mu;
+                        am += wk * x;
+                        av += wk * (dif * dif);
+                        ac += wk;
+                    }
+                }
+                // waves in order: sh[w*64 + l] (mean sums), sh2 (variance sums); the count from lane 0
+                __syncthreads();
+                sh[tid] = am;
+                sh2[tid] = av;
+                __syncthreads();
+                if (tid < 64) {
+                    double sm = 0.0, sv = 0.0;
+                    for (int q = 0; q < NW; q++) {
+                        sm += sh[q * 64 + tid];
+                        sv += sh2[q * 64 + tid];
+                    }
+                    if (tid < D) {
+                        num_mu[(size_t)g * D + tid] = sm;
+                        num_var[(size_t)g * D + tid] = sv;
+                    }
+                }
+                __syncthreads();
+                sh[tid] = ac;
+                __syncthreads();
+                if (tid == 0) {
+                    double sc = 0.0;
+                    for (int q = 0; q < NW; q++) sc += sh[q * 64];
+                    num_c[g] = sc;
                 }
             }
         } else {
@@ -926,11 +992,28 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
             for (int d0 = 0; d0 < D1; d0 += 128) {
                 const int d = d0 + e;
                 double vm = 0.0, vv = 0.0;
-                if (d < D1)
-                    for (int p = half; p < a.P1; p += SL) {
-                        vm += a.part_mu[(size_t)p * E + (size_t)g * D1 + d];
-                        vv += a.part_var[(size_t)p * E + (size_t)g * D1 + d];
+                if (d < D1) {
+                    // four independent chains (fixed assignment of partials to chains: reproducible)
+                    double m1 = 0.0, m2 = 0.0, m3 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+                    const double *pmu = a.part_mu + (size_t)g * D1 + d, *pva = a.part_var + (size_t)g * D1 + d;
+                    int p = half;
+                    for (; p + 3 * SL < a.P1; p += 4 * SL) {
+                        vm += pmu[(size_t)p * E];
+                        vv += pva[(size_t)p * E];
+                        m1 += pmu[(size_t)(p + SL) * E];
+                        v1 += pva[(size_t)(p + SL) * E];
+                        m2 += pmu[(size_t)(p + 2 * SL) * E];
+                        v2 += pva[(size_t)(p + 2 * SL) * E];
+                        m3 += pmu[(size_t)(p + 3 * SL) * E];
+                        v3 += pva[(size_t)(p + 3 * SL) * E];
                     }
+                    for (; p < a.P1; p += SL) {
+                        vm += pmu[(size_t)p * E];
+                        vv += pva[(size_t)p * E];
+                    }
+                    vm = (vm + m1) + (m2 + m3);
+                    vv = (vv + v1) + (v2 + v3);
+                }
                 sh[tid] = vm;
                 sh2[tid] = vv;
                 __syncthreads();

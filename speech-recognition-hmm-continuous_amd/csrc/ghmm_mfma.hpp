@@ -96,6 +96,19 @@ __device__ inline int tile_offset_choice(const double *cond16)
     return w;
 }
 
+// How a Gaussian's statistics are taken (k_mixstats_mfma / k_mixstats / k_reduce_all):
+//   0  well-conditioned around the global offset: the expanded sums of the matrix-core kernel
+//   1  ill-conditioned only because EVERY variance sits at the 1e-5 floor (a component that EM
+//      has collapsed onto one frame, or onto a few identical ones): still the expanded sums —
+//      its variance statistic is far below the floor, where any value gives the same M-step —
+//      checked by k_reduce_all, which recomputes the Gaussian exactly if the check fails
+//   2  ill-conditioned otherwise: the direct-form sums of the vector-ALU kernel
+__device__ inline int stats_class(bool real, double cond_global, double wide_coefficients)
+{
+    if (!real || !(cond_global > COND_MAX)) return 0;
+    return wide_coefficients == 0.0 ? 1 : 2;
+}
+
 // ghmm_model_set path: the choice from the model itself.  tnext / otile: what the next
 // preparation will use (k_prepare_mfma right behind this kernel).
 __global__ void __launch_bounds__(64)
@@ -142,9 +155,9 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
                double *__restrict__ Wm, double *__restrict__ wkp, double *__restrict__ logwkp,
                int *__restrict__ gmap, double *__restrict__ condt, double *__restrict__ condg,
                int *__restrict__ anyflag, int *__restrict__ sflag, int epoch,
-               double *__restrict__ dtile, int *__restrict__ tshift)
+               double *__restrict__ dtile, int *__restrict__ tshift, int *__restrict__ scls)
 {
-    __shared__ double sh0[64], sh1[64];
+    __shared__ double sh0[64], sh1[64], sh2[64];
     const int gp = blockIdx.x, t = threadIdx.x;
     const int c = gp >> 4, j = gp & 15, KS = DP / 2;
     const int i = gp / Mp, m = gp % Mp;
@@ -152,11 +165,12 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
     const int g = real ? i * M + m : -1;
     double *Wc = Wm + (size_t)c * KS * 64;
     const bool shifted = tnext[c] != 0; // this tile has its own offset (k_prepare_tiles / k_reduce_all)
-    double c0 = 0.0, cg = 0.0;
+    double c0 = 0.0, cg = 0.0, wide = 0.0; // wide: coefficients whose variance is above the floor
     for (int d = t; d < DP; d += 64) {
         double bc = 0.0, ac = 0.0;
         if (real && d < D) {
             const double mraw = mean[(size_t)g * D + d], iv = inv_var[(size_t)g * D + d];
+            wide += iv < 0.99 / FLOOR ? 1.0 : 0.0;
             const double mu = mraw - oglob[d];
             const double mt = mraw - (shifted ? otile[(size_t)c * DP + d] : oglob[d]);
             bc = mt * iv;
@@ -171,17 +185,20 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
     }
     sh0[t] = cg;
     sh1[t] = c0;
+    sh2[t] = wide;
     __syncthreads();
     for (int k = 32; k > 0; k >>= 1) {
         if (t < k) {
             sh0[t] += sh0[t + k];
             sh1[t] += sh1[t + k];
+            sh2[t] += sh2[t + k];
         }
         __syncthreads();
     }
     if (t == 0) {
         cg = sh0[0];
         c0 = sh1[0];
+        scls[gp] = stats_class(real, cg, sh2[0]);
         gmap[gp] = g;
         wkp[gp] = real ? wk[g] : 0.0;
         logwkp[gp] = real ? logwk[g] : -1.0e300; // padding never wins a max, exp() of it is 0
@@ -194,7 +211,7 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
         // (flag[0] == the model's preparation count means "flagged now": nothing has to
         // clear it, every writer of one preparation stores the same value)
         if (real && c0 > COND_MAX) anyflag[0] = epoch;
-        if (real && cg > COND_MAX) sflag[0] = epoch;
+        if (scls[gp] == 2) sflag[0] = epoch;
     }
 }
 
@@ -215,7 +232,7 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
              double *__restrict__ logwkp, int *__restrict__ gmap, double *__restrict__ condg,
              int *__restrict__ anyflag, int epoch, const double *__restrict__ otile,
              const int *__restrict__ tnext, double *__restrict__ condt, double *__restrict__ dtile,
-             int *__restrict__ tshift, int *__restrict__ sflag, int delta)
+             int *__restrict__ tshift, int *__restrict__ sflag, int delta, int *__restrict__ scls)
 {
     extern __shared__ double vs[]; // [lds_doubles] staging of mstep_state | og[DP] | red[MSF_THREADS]
     double *og = vs + lds_doubles, *red = og + DP;
@@ -266,12 +283,13 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
         // the tile's own offset (chosen by k_reduce_all from the model before this M-step: a
         // collapsed component does not move any more) or the data's centre
         const bool shifted = tnext[ct] != 0;
-        double cg = 0.0, c0 = 0.0;
+        double cg = 0.0, c0 = 0.0, wide = 0.0;
         for (int d = l; d < DP; d += 64) {
             double bc = 0.0, ac = 0.0, dt = 0.0;
             if (d < D) dt = shifted ? otile[(size_t)ct * DP + d] - og[d] : 0.0;
             if (real && d < D) {
                 const double mu = mean[(size_t)g * D + d] - og[d], iv = inv_var[(size_t)g * D + d];
+                wide += iv < 0.99 / FLOOR ? 1.0 : 0.0;
                 const double mt = mu - dt;
                 bc = mt * iv;
                 ac = -0.5 * iv;
@@ -287,6 +305,7 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
         for (int o = 32; o > 0; o >>= 1) {
             cg += __shfl_xor(cg, o, 64);
             c0 += __shfl_xor(c0, o, 64);
+            wide += __shfl_xor(wide, o, 64);
         }
         if (l == 0) {
             gmap[gp] = g;
@@ -296,8 +315,10 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
             condg[gp] = real ? cg : 0.0;
             condt[gp] = real ? c0 : 0.0;
             tshift[ct] = shifted ? 1 : 0;
+            const int cls = stats_class(real, cg, wide);
+            scls[gp] = cls;
             if (real && c0 > COND_MAX) anyflag[0] = epoch;
-            if (real && cg > COND_MAX) sflag[0] = epoch;
+            if (cls == 2) sflag[0] = epoch;
         }
     }
 }
@@ -642,13 +663,14 @@ __device__ __host__ inline int slot_row(int p) { return (p >> 2) + 4 * (p & 3); 
 __host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves)
 {
     const int KS = DP / 2, XS = DP + 2;
-    return (size_t)TC * KS * 64 * 8 + (size_t)waves * 16 * XS * 8 + (size_t)DP * 8 +
+    return (size_t)TC * KS * 64 * 8 + (size_t)waves * 16 * XS * 8 + (size_t)DP * 8 + // (see the kernel)
            (size_t)TC * 16 * 8 + (size_t)TC * DP * 8 + 32 * 8 + (size_t)TC * 16 * 4 + (size_t)TC * 4 * 2 + 64;
 }
 
 // OUT 0: b (recogniser, RF:860-889); 1: b and posteriors (trainer, TF:1749-1783);
 // 2: log b for the Viterbi lattice, m + log(sum exp(e - m)) like the oracle's definition
-// (wkp then holds log wk).  tfull[tile]: the tile's 16 slots are 16 consecutive real Gaussians
+// (wkp then holds log wk).  condt: conditioning of every padded Gaussian around its tile's offset
+// (slots beyond COND_MAX are re-evaluated in direct form where their density is not 0).  tfull[tile]: the tile's 16 slots are 16 consecutive real Gaussians
 // starting at an even index and G is even (its posteriors go out as aligned 16-byte stores).
 template <int KS, int MP, int OUT>
 __global__ void __launch_bounds__(ems_waves(MP) * WAVE)
@@ -656,11 +678,11 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                  const double *__restrict__ Wm, const double *__restrict__ oglob,
                  const double *__restrict__ wkp, const int *__restrict__ gmap,
                  double *__restrict__ b, double *__restrict__ post,
-                 const int *__restrict__ anyflag, int epoch, const double *__restrict__ dtile,
-                 const int *__restrict__ tshift, const int *__restrict__ tfull)
+                 const double *__restrict__ dtile, const int *__restrict__ tshift,
+                 const int *__restrict__ tfull, const double *__restrict__ condt,
+                 const double *__restrict__ mean, const double *__restrict__ inv_var)
 {
     extern __shared__ double lds[];
-    if (anyflag[0] == epoch) return; // an ill-conditioned Gaussian somewhere: k_emission_mfma does the job
     // slab row stride 2 * odd doubles: the 32 lanes of a ds_read_b64 group (16 frames x 2
     // k-columns) then fall on 32 different bank pairs
     constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 2, WV = ems_waves(MP);
@@ -724,7 +746,11 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     }
     for (int k = tid; k < tc; k += WV * WAVE) {
         tsl[k] = tshift[c0 + k];
-        tfl[k] = tfull[c0 + k];
+        // low bit: whole tile of consecutive Gaussians; bits 16..31: slots whose Gaussian is too
+        // ill-conditioned for the expanded form even around the tile's offset (condt)
+        unsigned bm = 0;
+        for (int pp = 0; pp < 16; pp++) bm |= (condt[(c0 + k) * 16 + pp] > COND_MAX ? 1u : 0u) << (16 + pp);
+        tfl[k] = (int)(bm | (tfull[c0 + k] != 0 ? 1u : 0u));
     }
     for (int k = tid; k < DP; k += WV * WAVE) ol[k] = k < D ? oglob[k] : 0.0;
     for (int k = tid; k < tc * DP; k += WV * WAVE) dl[k] = dtile[(size_t)c0 * DP + k];
@@ -732,13 +758,15 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     __syncthreads();
     // per-tile flags of the chunk as bit masks in scalar registers (TC <= 32): no LDS round trip
     // per tile for them
-    unsigned shm = 0, fum = 0;
+    unsigned shm = 0, fum = 0, bdm = 0;
     for (int k = 0; k < tc; k++) {
         shm |= (tsl[k] != 0 ? 1u : 0u) << k;
-        fum |= (tfl[k] != 0 ? 1u : 0u) << k;
+        fum |= ((unsigned)tfl[k] & 1u) << k;
+        bdm |= (((unsigned)tfl[k] >> 16) != 0 ? 1u : 0u) << k;
     }
     shm = (unsigned)__builtin_amdgcn_readfirstlane((int)shm);
     fum = (unsigned)__builtin_amdgcn_readfirstlane((int)fum);
+    bdm = (unsigned)__builtin_amdgcn_readfirstlane((int)bdm); // tiles that hold such a slot
     double *xw = xl + w * 16 * XS;
     // constant columns of the slab: the 1 at column D, zeros beyond
     for (int k = l; k < 16 * (XS - D); k += WAVE) {
@@ -857,6 +885,33 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                     }
                 }
                 // acc[r]: exponent of slot 4 kq + r at frame l & 15
+                if ((bdm >> (ct + tt)) & 1u) {
+                    // A slot whose Gaussian is ill-conditioned even around the tile's offset (a
+                    // second variance-floored component in the tile): its expanded exponent is
+                    // off by up to ~1e-7 absolutely.  Where that exponent is far below the
+                    // underflow of exp() the density is 0 either way (TF:1834); only for the
+                    // few frames next to such a component is it taken again in the reference's
+                    // direct form (x - mu) inv (x - mu), TF:1829-1832, from the raw frame.
+                    const unsigned bm = (unsigned)tfl[ct + tt] >> 16;
+                    bool need = false;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) need |= ((bm >> (4 * kq + r)) & 1u) && acc[r] > -760.0;
+                    if (__any(need)) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (((bm >> (4 * kq + r)) & 1u) && acc[r] > -760.0 && fok) {
+                                const int gq = gml[(ct + tt) * 16 + 4 * kq + r];
+                                const double *mu = mean + (size_t)gq * D, *iv = inv_var + (size_t)gq * D;
+                                const double *xf = X + fr * D;
+                                double aux = 0.0;
+                                for (int d = 0; d < D; d++) {
+                                    const double dif = xf[d] - mu[d];
+                                    aux += dif * iv[d] * dif;
+                                }
+                                acc[r] = -0.5 * aux;
+                            }
+                    }
+                }
                 if (OUT == 2) {
                     // wkl holds log(wk) here: keep the exponents, exponentiate after the max
                     const v4d wk4 = *(const v4d *)(wkl + (ct + tt) * 16 + 4 * kq);

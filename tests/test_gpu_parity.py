@@ -752,6 +752,62 @@ def test_two_ranks_on_one_gpu_equal_one_rank(G, ctx):
         o.close()
 
 
+def test_collapsed_components_sharing_a_tile(G, ctx):
+    """Variance-floored "needle" components (every variance at 1e-5, det = 1e-195: what EM from the
+    reference's initial model produces within two iterations), three of them in ONE tile
+    of 16 Gaussians and two more elsewhere, each sitting exactly on a frame of the corpus.  The
+    emission kernel takes them through the expanded form and re-evaluates them in the reference's
+    direct form only next to their frames; their statistics come from the matrix-core sums, checked
+    against the floor.  Everything against the oracle, then two more EM iterations."""
+    hm, X, lens = synth_case(G, 10, 8, 39, [300, 211, 128, 77], perturb=0.05)
+    # each needle on a frame that its state certainly occupies (else its num_c is 0 and the
+    # reference's own M-step divides 0 by 0)
+    _, d0 = O.estep(hm, X, lens)
+    occ = d0["alpha"] * d0["beta"] / d0["scale"][:, None]
+    used = set()
+    for (i, j) in ((0, 0), (0, 3), (1, 2), (4, 7), (9, 1)):
+        order = np.argsort(-occ[:, i])
+        f = next(int(t) for t in order if int(t) not in used)
+        used.add(f)
+        hm.mean[i, j] = X[f]
+        hm.inv_var[i, j] = 1.0 / 1e-5
+        hm.det[i, j] = 1e-5 ** 39
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    F = corpus.frames
+    ref_stats, ref = O.estep(hm, X, lens)
+    ctx.estep(model, corpus, stats)
+    assert np.isfinite(ref["loglik"]).all()
+    assert_frames(ctx.fetch(G.BUF_B, (F, 10)), ref["b"], "b")
+    assert_frames(ctx.fetch(G.BUF_POST, (F, 80)), ref["post"].reshape(F, -1), "post")
+    assert_close(ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ref["loglik"], what="loglik")
+    got, refs = G.split_stats(stats.download(), 10, 8, 39), G.split_stats(ref_stats, 10, 8, 39)
+    for k in refs:
+        assert_close(got[k], refs[k], what="stats." + k)
+    cur = hm
+    for it in range(3):
+        ctx.mstep(model, stats)
+        cur = O.mstep(cur, ref_stats)
+        for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), model.get().arrays(), cur.arrays()):
+            assert_close(a, b, rtol=1e-7, what=f"iteration {it} model.{nm}")
+        ref_stats, _ = O.estep(cur, X, lens, dumps=False)
+        if not np.isfinite(ref_stats).all():
+            assert it > 0          # parity is defined where the reference stays finite (SURVEY §0)
+            break
+        ctx.estep(model, corpus, stats)
+        assert_close(stats.download(), ref_stats, rtol=1e-7, what=f"iteration {it} statistics")
+    # the Viterbi lattice takes the same kernel with log b
+    path, score = ctx.viterbi(model, corpus)
+    o = 0
+    hm_now = model.get()
+    for T in lens:
+        p_ref, s_ref = O.viterbi(hm_now, X[o:o + T])
+        assert np.array_equal(path[o:o + T], p_ref)
+        o += T
+    for o_ in (model, corpus, stats):
+        o_.close()
+
+
 # ------------------------------------------------ fuzz against the oracle (seeded shapes)
 
 def fuzz_estep_case(G, ctx, seed):
