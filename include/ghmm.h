@@ -76,7 +76,8 @@ enum {
     GHMM_OPT_ROBUST = 2,
     /* 0 auto, 1 vector-ALU kernels and the reference's order of the recursions (calc_alpha,
      * then calc_beta scaled by its c_t, one pass each), 2 MFMA (f64 16x16x4) kernels and the
-     * forward / backward recursions side by side (what auto picks) */
+     * forward / backward recursions side by side (what auto picks); 3 is a measurement variant
+     * of 2 (statistics kernel with its operands straight from HBM instead of staged through LDS) */
     GHMM_OPT_KERNELS = 3,
     /* 1: bracket every kernel with HIP events on the context's stream */
     GHMM_OPT_TIMING = 4,

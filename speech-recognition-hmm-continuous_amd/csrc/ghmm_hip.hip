@@ -363,7 +363,7 @@ extern "C" int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value)
         ctx->robust = value;
         break;
     case GHMM_OPT_KERNELS:
-        ARG_CHECK(value >= 0 && value <= 2, "kernels must be 0, 1 or 2");
+        ARG_CHECK(value >= 0 && value <= 3, "kernels must be 0..3");
         ctx->kernels = value;
         break;
     case GHMM_OPT_TIMING:
