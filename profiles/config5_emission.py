@@ -1,7 +1,8 @@
-"""BASELINE configs[4] shape (2000 tied states x 16 mix, 39-d), emission only: parity of a
-small slice against the oracle and the kernel's rate on a larger one.
-usage: python profiles/config5_emission.py [frames]"""
-import ctypes
+"""BASELINE configs[4] (2 000 tied states x 16 mix, 39-d, 1 M frames), emission only: parity of a
+slice against the oracle (oracle/ghmm_oracle.c orc_emission = calc_symbol_probab / calc_gaus,
+TF:1749-1841) and the kernel's rate over the full 1 M frames (the same workload as bench.py's
+"config5" extra and tests/test_gpu_parity.py::test_config5_*).
+usage: python profiles/config5_emission.py [frames]   -> profiles/r2_config5.txt"""
 import sys
 import time
 
@@ -10,37 +11,33 @@ import numpy as np
 sys.path.insert(0, "tests")
 from _load import load_pkg
 import oracle_lib as O
+import test_gpu_parity as T
 
 G = load_pkg().ghmm
-N, M, D = 2000, 16, 39
-rng = np.random.default_rng(5)
-mean = rng.normal(0, 2, (N, M, D))
-std = rng.uniform(0.5, 1.5, (N, M, D))
-hm = G.HostModel(np.eye(N), np.full((N, M), 1.0 / M), mean, 1.0 / std**2, np.prod(std**2, axis=2))
-F = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-X = rng.normal(0, 2.2, (F, D))
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+hm, centre = T._config5_model(G)
+N, M, D = hm.N, hm.M, hm.D
+X = T._config5_frames(centre, F, seed=2)
 ctx = G.Context(0)
 model = ctx.model(hm)
-small = ctx.corpus(X[:48], [48])
+small = ctx.corpus(X[:96], [96])
 ctx.emission(model, small, False)
-got = ctx.fetch(G.BUF_B, (48, N))
-b = np.zeros((48, N))
-L = O.lib()
-L.orc_emission.restype = None
-L.orc_emission.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_double)] * 7
-L.orc_emission(N, M, D, 48, O._d(X[:48].copy()), O._d(hm.c), O._d(hm.mean), O._d(hm.inv_var),
-               O._d(hm.det), O._d(b), None)
-err = np.abs(got - b) / np.maximum(np.abs(b), 1e-300)
-print("parity 48 frames x 32000 Gaussians: max rel err", err.max())
+got = ctx.fetch(G.BUF_B, (96, N))
+ref = O.emission(hm, X[:96])
+err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+print(f"parity, 96 frames x {N * M} Gaussians against the oracle: max relative error of b {err.max():.3e}")
 corpus = ctx.corpus(X, [F])
 ctx.set_option(G.OPT_TIMING, 1)
 ctx.emission(model, corpus, False)
 ctx.sync()
-ctx.kernel_times_reset()
-t = time.perf_counter()
-ctx.emission(model, corpus, False)
-ctx.sync()
-dt = time.perf_counter() - t
-flop = 2.0 * F * 80 * N * M
-print(f"{F} frames: {dt*1e3:.1f} ms, {F/dt/1e6:.2f} Mframes/s, {flop/dt/1e12:.1f} TFLOP/s f64 (MFMA form)",
-      ctx.kernel_times()["emission"])
+for rep in range(3):
+    ctx.kernel_times_reset()
+    t = time.perf_counter()
+    ctx.emission(model, corpus, False)
+    ctx.sync()
+    dt = time.perf_counter() - t
+    ms = ctx.kernel_times()["emission"][0]
+    flop = 2.0 * F * 80 * N * M
+    print(f"{F} frames x {N} states x {M} mix: kernel {ms:.2f} ms (wall {dt * 1e3:.2f}), "
+          f"{flop / (ms * 1e-3) / 1e12:.2f} TFLOP/s f64 on the matrix pipe = "
+          f"{flop / (ms * 1e-3) / 1e12 / 78.6:.3f} of the 78.6 TFLOP/s peak; output {8 * F * N / 1e9:.1f} GB")
