@@ -225,6 +225,21 @@ int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *loglik_host
  * differ).  loglik_host[k*U + u] = log P(utterance u | model k).  Synchronises. */
 int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_models, ghmm_corpus *c,
                      double *loglik_host);
+/* Several feature streams (param_number P > 1): every recursion runs on the product over streams
+ * of the emission densities, b_i(t) = prod_p b^p_i(t) in stream order (calc_alpha TF:1406-1409 /
+ * 1429-1432, calc_beta TF:1501-1504, calc_transition_probab TF:1607-1610); calc_symbol_probab
+ * (TF:278-288) and calc_mix_param (TF:306-315) run once per stream with that stream's own
+ * mixtures and posteriors.  models[p] / corpora[p] / stats[p] = stream p: same states, same
+ * utterances and lengths, own M_p and D_p; the transitions are models[0]'s.  stats[p] has the
+ * single-stream layout (the common sums are written into every one), so that ghmm_mstep(models[p],
+ * stats[p]) for every p is the M-step (TF:332-346: all of them write the same A).  The product
+ * b is what GHMM_BUF_B then holds.  GHMM_OPT_ROBUST is not available with several streams. */
+int ghmm_estep_streams(ghmm_ctx *ctx, ghmm_model *const *models, ghmm_corpus *const *corpora,
+                       int n_streams, ghmm_stats *const *stats);
+/* forward score per utterance of a P-stream model (RF:349-366) */
+int ghmm_score_streams(ghmm_ctx *ctx, ghmm_model *const *models, ghmm_corpus *const *corpora,
+                       int n_streams, double *loglik_host);
+
 /* Max-plus lattice with the reference's one-hot start (RF:249-251) and
  * final-state termination (TF:1487, TF:1549); ties take the lowest predecessor.
  * ABSENT from the reference: defined by oracle/.
@@ -297,6 +312,13 @@ int ghmm_host_model_alloc(ghmm_host_model *hm, int N, int M, int D);
 void ghmm_host_model_free(ghmm_host_model *hm);
 int ghmm_hmm_read(const char *path, ghmm_host_model *hm);
 int ghmm_hmm_write(const char *path, const ghmm_host_model *hm, int len_bytes);
+/* The same for models of several feature streams (the reference's param_number P, TF:2084-2099:
+ * int M[P], int D[P], then per stream the states' mixtures): hm[p] = stream p with its own M and
+ * D; word, N and A are common (the reader fills them into every hm[p]).  The reader takes up
+ * to max_streams (<= GHMM_MAX_STREAMS) and reports the file's count. */
+#define GHMM_MAX_STREAMS 8
+int ghmm_hmm_read_streams(const char *path, ghmm_host_model *hm, int max_streams, int *n_streams);
+int ghmm_hmm_write_streams(const char *path, const ghmm_host_model *hm, int n_streams, int len_bytes);
 
 /* creating_initial_model TF:732-1317 (uniform segmentation, LBG splitting with
  * factors 1.005/0.995, three k-means passes, per-cell variance floored at 1e-5)

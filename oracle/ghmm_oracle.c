@@ -362,6 +362,154 @@ int orc_train(int N, int M, int D, int delta, double threshold, int max_iter, in
     return it;
 }
 
+/* ------------------------------------------------- several feature streams
+ * param_number P > 1: every recursion takes the product over streams of the emission
+ * densities, `product = 1.0; for (l < P) product *= symbol_probab[l][i][t]` (calc_alpha
+ * TF:1406-1409 / 1429-1432, calc_beta TF:1501-1504, calc_transition_probab TF:1607-1610), i.e.
+ * b_i(t) = ((b^0 b^1) b^2) ... in stream order; calc_symbol_probab (TF:278-288) and calc_mix_param
+ * (TF:306-315) run once per stream with that stream's own mixtures and posteriors; the
+ * transition sums, den_c (TF:300), log P and the exemplar count are common.  stats[p] has the
+ * single-stream layout for (N, M[p], D[p]); the common entries are written into every one. */
+int orc_estep_streams(int P, int N, const int *M, const int *D, int delta, const double *A,
+                      const double *const *c, const double *const *mean,
+                      const double *const *inv_var, const double *const *det,
+                      const double *const *X, const int32_t *len, int n_utt, double *const *stats,
+                      double *o_b, double *o_loglik)
+{
+    int Tmax = 0, Gmax = 0;
+    for (int u = 0; u < n_utt; u++)
+        if (len[u] > Tmax) Tmax = len[u];
+    for (int p = 0; p < P; p++)
+        if (N * M[p] > Gmax) Gmax = N * M[p];
+    double *b = malloc(sizeof(double) * (size_t)Tmax * N);
+    double *bp = malloc(sizeof(double) * (size_t)Tmax * N);
+    double **post = malloc(sizeof(double *) * (size_t)P);
+    double *alpha = malloc(sizeof(double) * (size_t)Tmax * N);
+    double *beta = malloc(sizeof(double) * (size_t)Tmax * N);
+    double *scale = malloc(sizeof(double) * (size_t)Tmax);
+    int bad = !b || !bp || !post || !alpha || !beta || !scale;
+    for (int p = 0; post && p < P; p++) {
+        post[p] = malloc(sizeof(double) * (size_t)Tmax * N * M[p]);
+        if (!post[p]) bad = 1;
+    }
+    if (bad) return 1; /* (test infrastructure: the leak on this path is accepted) */
+    for (int p = 0; p < P; p++) memset(stats[p], 0, sizeof(double) * orc_stats_len(N, M[p], D[p]));
+    /* the common sums are accumulated in stats[0] and copied at the end */
+    double *num_a = stats[0], *den_a = num_a + (size_t)N * N, *den_c = den_a + N;
+    double ll = 0.0, nu = 0.0;
+    size_t f0 = 0;
+    for (int u = 0; u < n_utt; u++) {
+        int T = len[u];
+        if (T > 0) {
+            for (int p = 0; p < P; p++) {
+                orc_emission(N, M[p], D[p], T, X[p] + f0 * D[p], c[p], mean[p], inv_var[p], det[p],
+                             p == 0 ? b : bp, post[p]);
+                if (p > 0)
+                    for (size_t k = 0; k < (size_t)T * N; k++) b[k] *= bp[k];
+            }
+            orc_forward(N, T, A, b, alpha, scale);
+            orc_backward(N, T, A, b, scale, beta);
+            orc_acc_trans(N, T, delta, A, b, alpha, beta, scale, num_a, den_a);
+            orc_acc_den_mix(N, T, alpha, beta, scale, den_c);
+            for (int p = 0; p < P; p++) {
+                int G = N * M[p];
+                double *num_c = stats[p] + (size_t)N * N + 2 * (size_t)N, *num_mu = num_c + G;
+                double *num_var = num_mu + (size_t)G * D[p];
+                for (int t = 0; t < T; t++)
+                    orc_acc_mix_frame(N, M[p], D[p], X[p] + (f0 + (size_t)t) * D[p],
+                                      alpha + (size_t)t * N, beta + (size_t)t * N, scale[t],
+                                      post[p] + (size_t)t * G, mean[p], num_c, num_mu, num_var);
+            }
+            double pr = orc_loglik(T, scale, alpha[(size_t)(T - 1) * N + (N - 1)]);
+            ll += pr;
+            if (o_loglik) o_loglik[u] = pr;
+            if (o_b) memcpy(o_b + f0 * N, b, sizeof(double) * (size_t)T * N);
+        }
+        nu += 1.0;
+        f0 += (size_t)T;
+    }
+    for (int p = 0; p < P; p++) {
+        size_t n = orc_stats_len(N, M[p], D[p]);
+        if (p > 0) memcpy(stats[p], stats[0], sizeof(double) * ((size_t)N * N + 2 * (size_t)N));
+        stats[p][n - 2] = ll;
+        stats[p][n - 1] = nu;
+    }
+    for (int p = 0; p < P; p++) free(post[p]);
+    free(b); free(bp); free(post); free(alpha); free(beta); free(scale);
+    return 0;
+}
+
+/* EM driver for P streams, TF:238-358: one transition update, one updating_mix_param + calc_det +
+ * inv_matrix per stream (TF:332-346).  Model arrays updated in place; A is common. */
+int orc_train_streams(int P, int N, const int *M, const int *D, int delta, double threshold,
+                      int max_iter, int fixed_iter, double *A, double *const *c, double *const *mean,
+                      double *const *inv_var, double *const *det, const double *const *X,
+                      const int32_t *len, int n_utt, double *mean_loglik, double *loglik_trace)
+{
+    double **stats = malloc(sizeof(double *) * (size_t)P);
+    if (!stats) return -1;
+    for (int p = 0; p < P; p++) {
+        stats[p] = malloc(sizeof(double) * orc_stats_len(N, M[p], D[p]));
+        if (!stats[p]) return -1;
+    }
+    double old = 1.0, probab = 0.0, var;
+    int it = 0, more;
+    do {
+        it++;
+        if (orc_estep_streams(P, N, M, D, delta, A, (const double *const *)c, (const double *const *)mean,
+                              (const double *const *)inv_var, (const double *const *)det, X, len, n_utt,
+                              stats, NULL, NULL))
+            return -1;
+        probab = stats[0][orc_stats_len(N, M[0], D[0]) - 2];
+        if (loglik_trace) loglik_trace[it - 1] = probab;
+        var = fabs((old - probab) / old);
+        if (fixed_iter || var > threshold) {
+            old = probab;
+            const double *num_a = stats[0], *den_a = num_a + (size_t)N * N, *den_c = den_a + N;
+            orc_update_trans(N, num_a, den_a, A);
+            for (int p = 0; p < P; p++) {
+                int G = N * M[p];
+                const double *num_c = stats[p] + (size_t)N * N + 2 * (size_t)N, *num_mu = num_c + G;
+                const double *num_var = num_mu + (size_t)G * D[p];
+                orc_update_mix(N, M[p], D[p], den_c, num_c, num_mu, num_var, c[p], mean[p],
+                               inv_var[p], det[p]);
+            }
+        }
+        if (fixed_iter)
+            more = it < max_iter;
+        else
+            more = var > threshold && (max_iter <= 0 || it < max_iter);
+    } while (more);
+    if (mean_loglik) *mean_loglik = probab / (double)n_utt;
+    for (int p = 0; p < P; p++) free(stats[p]);
+    free(stats);
+    return it;
+}
+
+/* Recogniser score of one utterance under one P-stream model, RF:349-366 */
+double orc_score_streams(int P, int N, const int *M, const int *D, int T, const double *A,
+                         const double *const *c, const double *const *mean,
+                         const double *const *inv_var, const double *const *det,
+                         const double *const *X)
+{
+    double *b = malloc(sizeof(double) * (size_t)T * N);
+    double *bp = malloc(sizeof(double) * (size_t)T * N);
+    double *alpha = malloc(sizeof(double) * (size_t)T * N);
+    double *scale = malloc(sizeof(double) * (size_t)T);
+    double pr = NAN;
+    if (b && bp && alpha && scale) {
+        for (int p = 0; p < P; p++) {
+            orc_emission(N, M[p], D[p], T, X[p], c[p], mean[p], inv_var[p], det[p], p == 0 ? b : bp, NULL);
+            if (p > 0)
+                for (size_t k = 0; k < (size_t)T * N; k++) b[k] *= bp[k];
+        }
+        orc_forward(N, T, A, b, alpha, scale);
+        pr = orc_loglik(T, scale, alpha[(size_t)(T - 1) * N + (N - 1)]);
+    }
+    free(b); free(bp); free(alpha); free(scale);
+    return pr;
+}
+
 /* Recogniser score of one utterance under one model, RF:354-366 */
 double orc_score(int N, int M, int D, int T, const double *A, const double *c,
                  const double *mean, const double *inv_var, const double *det, const double *X)

@@ -77,6 +77,11 @@ struct ghmm_ctx {
     ghmm_corpus *last_c = nullptr;
     int slots = 0;             // partial-sum slots filled by the last backward / combine pass
     double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr;
+    // several feature streams: the stream being evaluated (b^p) and every stream's posteriors
+    double *b_stream = nullptr;
+    size_t cap_b_stream = 0;
+    std::vector<double *> post_s;
+    std::vector<size_t> cap_post_s;
     unsigned char *psi = nullptr;
     unsigned char *path = nullptr; // Viterbi state per frame (N <= 255): one byte on the device
     // shape of what the workspace currently holds (for ghmm_fetch)
@@ -327,8 +332,10 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
                     ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb,
-                    ctx->lpart,   ctx->logk};
+                    ctx->lpart,   ctx->logk,      ctx->b_stream};
     for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    for (double *p : ctx->post_s)
         if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
         if (ctx->pin[k]) (void)hipHostFree(ctx->pin[k]);
@@ -1530,6 +1537,112 @@ extern "C" int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *
     if (c->U)
         HIP_TRY(hipMemcpyAsync(loglik_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,
                                ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
+// ------------------------------------------------------ several feature streams
+
+static int check_streams(ghmm_ctx *ctx, ghmm_model *const *models, ghmm_corpus *const *corpora, int P)
+{
+    ARG_CHECK(models && corpora && P >= 1 && P <= GHMM_MAX_STREAMS, "bad stream arguments");
+    for (int p = 0; p < P; p++) {
+        int rc = check_pair(models[p], corpora[p]);
+        if (rc) return rc;
+        if (models[p]->N != models[0]->N) {
+            ghmm_set_error("stream %d has %d states, stream 0 has %d", p, models[p]->N, models[0]->N);
+            return GHMM_ERR_ARG;
+        }
+        if (corpora[p]->U != corpora[0]->U || corpora[p]->len != corpora[0]->len) {
+            ghmm_set_error("stream %d: utterance count or lengths differ from stream 0", p);
+            return GHMM_ERR_ARG;
+        }
+    }
+    if (P > 1 && ctx->robust) {
+        ghmm_set_error("GHMM_OPT_ROBUST is not available with several feature streams");
+        return GHMM_ERR_UNSUPPORTED;
+    }
+    return GHMM_OK;
+}
+
+// emission of every stream; ctx->b ends up holding the product, ctx->post_s[p] stream p's posteriors
+static int streams_emission(ghmm_ctx *ctx, ghmm_model *const *models, ghmm_corpus *const *corpora, int P,
+                            bool want_post)
+{
+    int rc;
+    const size_t FN = (size_t)corpora[0]->F * models[0]->N;
+    if ((int)ctx->post_s.size() < P) {
+        ctx->post_s.resize((size_t)P, nullptr);
+        ctx->cap_post_s.resize((size_t)P, 0);
+    }
+    for (int p = 0; p < P; p++) {
+        if ((rc = ws_frames(ctx, models[p], corpora[p], false))) return rc;
+        if (want_post &&
+            (rc = dev_grow(&ctx->post_s[p], &ctx->cap_post_s[p], (size_t)corpora[p]->F * models[p]->N * models[p]->M)))
+            return rc;
+    }
+    if ((rc = dev_grow(&ctx->b_stream, &ctx->cap_b_stream, FN))) return rc;
+    double *const b_all = ctx->b, *const post_own = ctx->post;
+    for (int p = 0; p < P && !rc; p++) {
+        ctx->b = p == 0 ? b_all : ctx->b_stream;
+        ctx->post = want_post ? ctx->post_s[p] : nullptr;
+        rc = run_emission(ctx, models[p], corpora[p], 0, want_post);
+        if (!rc && p > 0 && FN) {
+            long long blocks = ((long long)FN + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            kscope ks(ctx, GHMM_K_EMISSION);
+            hipLaunchKernelGGL(k_mul_streams, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (long long)FN,
+                               b_all, ctx->b_stream);
+            rc = launch_ok("k_mul_streams");
+        }
+    }
+    ctx->b = b_all;
+    ctx->post = post_own;
+    // the product belongs to stream 0's (model, corpus) pair as far as the row API is concerned
+    ctx->em_m = models[0];
+    ctx->em_c = corpora[0];
+    ctx->em_epoch = models[0]->epoch;
+    ctx->N = models[0]->N;
+    ctx->G = models[0]->N * models[0]->M;
+    return rc;
+}
+
+extern "C" int ghmm_estep_streams(ghmm_ctx *ctx, ghmm_model *const *models, ghmm_corpus *const *corpora,
+                                  int P, ghmm_stats *const *stats)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_streams(ctx, models, corpora, P))) return rc;
+    ARG_CHECK(stats, "null statistics");
+    for (int p = 0; p < P; p++)
+        if ((rc = check_stats(models[p], stats[p]))) return rc;
+    if (P == 1) return ghmm_estep(ctx, models[0], corpora[0], stats[0]);
+    if ((rc = streams_emission(ctx, models, corpora, P, true))) return rc;
+    if ((rc = ws_fb(ctx, models[0], corpora[0]))) return rc;
+    if ((rc = run_forward(ctx, models[0], corpora[0], true))) return rc;
+    if ((rc = run_backward(ctx, models[0], corpora[0], false))) return rc;
+    // calc_mix_param per stream (TF:306-315) with the common gamma; the transition sums, den_c,
+    // log P and the exemplar count go into every stream's vector
+    double *const post_own = ctx->post;
+    for (int p = 0; p < P && !rc; p++) {
+        ctx->post = ctx->post_s[p];
+        rc = run_accumulate(ctx, models[p], corpora[p], stats[p]);
+    }
+    ctx->post = post_own;
+    return rc;
+}
+
+extern "C" int ghmm_score_streams(ghmm_ctx *ctx, ghmm_model *const *models, ghmm_corpus *const *corpora,
+                                  int P, double *loglik_host)
+{
+    int rc = use(ctx);
+    if (rc || (rc = check_streams(ctx, models, corpora, P))) return rc;
+    if (P == 1) return ghmm_score(ctx, models[0], corpora[0], loglik_host);
+    ghmm_corpus *c = corpora[0];
+    ARG_CHECK(loglik_host || c->U == 0, "null destination");
+    if ((rc = streams_emission(ctx, models, corpora, P, false))) return rc;
+    if ((rc = ws_fb(ctx, models[0], c)) || (rc = run_forward(ctx, models[0], c))) return rc;
+    if (c->U)
+        HIP_TRY(hipMemcpyAsync(loglik_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return GHMM_OK;
 }

@@ -210,8 +210,10 @@ void ghmm_host_model_free(ghmm_host_model *hm)
     hm->A = hm->c = hm->mean = hm->inv_var = hm->det = NULL;
 }
 
-/* try to parse with a `lb`-byte length prefix; 0 = fits the file exactly */
-static int hmm_try(FILE *f, long size, int lb, ghmm_host_model *hm, const char *path)
+/* try to parse with a `lb`-byte length prefix; 0 = fits the file exactly.  Up to `max_p` feature
+   streams (the reference's param_number, TF:2084-2099): hm[p] = stream p, each with its own copy
+   of the word, N and A; *P_out = the file's stream count. */
+static int hmm_try(FILE *f, long size, int lb, ghmm_host_model *hm, int max_p, int *P_out, const char *path)
 {
     unsigned char raw[8] = {0};
     rewind(f);
@@ -220,52 +222,60 @@ static int hmm_try(FILE *f, long size, int lb, ghmm_host_model *hm, const char *
     for (int i = lb - 1; i >= 0; i--) len = (len << 8) | raw[i];
     if (len >= GHMM_MAX_WORD) return GHMM_ERR_FORMAT;
     char word[GHMM_MAX_WORD] = {0};
-    int32_t N = 0, P = 0, M = 0, D = 0;
+    int32_t N = 0, P = 0, M[GHMM_MAX_STREAMS], D[GHMM_MAX_STREAMS];
     if (fread(word, 1, (size_t)len, f) != (size_t)len) return GHMM_ERR_FORMAT;
     if (fread(&N, 4, 1, f) != 1 || fread(&P, 4, 1, f) != 1) return GHMM_ERR_FORMAT;
-    if (N <= 0 || N > 65536 || P <= 0 || P > 64) return GHMM_ERR_FORMAT;
-    if (P != 1) {
-        /* make sure it is a plausible multi-stream file before saying so */
-        ghmm_set_error("%s: %d feature streams; only param_number = 1 is built", path, P);
+    if (N <= 0 || N > 65536 || P <= 0 || P > GHMM_MAX_STREAMS) return GHMM_ERR_FORMAT;
+    if (fread(M, 4, (size_t)P, f) != (size_t)P || fread(D, 4, (size_t)P, f) != (size_t)P) return GHMM_ERR_FORMAT;
+    long expect = lb + (long)len + 8 + 8L * P + 8L * (long)N * N;
+    for (int p = 0; p < P; p++) {
+        if (M[p] <= 0 || M[p] > 65536 || D[p] <= 0 || D[p] > 65536) return GHMM_ERR_FORMAT;
+        expect += 8L * (long)N * ((long)M[p] + (long)M[p] * (2L * D[p] + 1));
+    }
+    if (expect != size) return GHMM_ERR_FORMAT;
+    if (P > max_p) {
+        ghmm_set_error("%s: %d feature streams, the caller takes %d", path, P, max_p);
         return GHMM_ERR_UNSUPPORTED;
     }
-    if (fread(&M, 4, 1, f) != 1 || fread(&D, 4, 1, f) != 1) return GHMM_ERR_FORMAT;
-    if (M <= 0 || M > 65536 || D <= 0 || D > 65536) return GHMM_ERR_FORMAT;
-    long expect = lb + (long)len + 16 +
-                  8L * ((long)N * N + (long)N * ((long)M + (long)M * (2L * D + 1)));
-    if (expect != size) return GHMM_ERR_FORMAT;
-    int rc = ghmm_host_model_alloc(hm, N, M, D);
-    if (rc) return rc;
-    memcpy(hm->word, word, GHMM_MAX_WORD);
-    int ok = fread(hm->A, 8, (size_t)N * N, f) == (size_t)N * N;
-    for (int i = 0; ok && i < N; i++) {
-        ok = fread(hm->c + (size_t)i * M, 8, (size_t)M, f) == (size_t)M;
-        for (int k = 0; ok && k < M; k++) {
-            size_t g = (size_t)i * M + k;
-            ok = fread(hm->mean + g * D, 8, (size_t)D, f) == (size_t)D &&
-                 fread(hm->det + g, 8, 1, f) == 1 &&
-                 fread(hm->inv_var + g * D, 8, (size_t)D, f) == (size_t)D;
-        }
+    int rc = GHMM_OK, ok = 1;
+    for (int p = 0; p < P; p++) memset(&hm[p], 0, sizeof hm[p]);
+    for (int p = 0; p < P && !rc; p++) {
+        rc = ghmm_host_model_alloc(&hm[p], N, M[p], D[p]);
+        if (!rc) memcpy(hm[p].word, word, GHMM_MAX_WORD);
     }
-    if (!ok) {
-        ghmm_host_model_free(hm);
-        return GHMM_ERR_IO;
+    if (!rc) {
+        ok = fread(hm[0].A, 8, (size_t)N * N, f) == (size_t)N * N;
+        for (int p = 1; p < P; p++) memcpy(hm[p].A, hm[0].A, sizeof(double) * (size_t)N * N);
+        for (int p = 0; ok && p < P; p++)
+            for (int i = 0; ok && i < N; i++) {
+                ok = fread(hm[p].c + (size_t)i * M[p], 8, (size_t)M[p], f) == (size_t)M[p];
+                for (int k = 0; ok && k < M[p]; k++) {
+                    size_t g = (size_t)i * M[p] + k;
+                    ok = fread(hm[p].mean + g * D[p], 8, (size_t)D[p], f) == (size_t)D[p] &&
+                         fread(hm[p].det + g, 8, 1, f) == 1 &&
+                         fread(hm[p].inv_var + g * D[p], 8, (size_t)D[p], f) == (size_t)D[p];
+                }
+            }
     }
+    if (rc || !ok) {
+        for (int p = 0; p < P; p++) ghmm_host_model_free(&hm[p]);
+        return rc ? rc : GHMM_ERR_IO;
+    }
+    *P_out = P;
     return GHMM_OK;
 }
 
-int ghmm_hmm_read(const char *path, ghmm_host_model *hm)
+int ghmm_hmm_read_streams(const char *path, ghmm_host_model *hm, int max_streams, int *n_streams)
 {
-    if (!path || !hm) return GHMM_ERR_ARG;
-    memset(hm, 0, sizeof *hm);
+    if (!path || !hm || !n_streams || max_streams <= 0) return GHMM_ERR_ARG;
     FILE *f = fopen(path, "rb");
     if (!f) {
         ghmm_set_error("file %s not found", path);
         return GHMM_ERR_IO;
     }
     long size = file_size(f);
-    int rc = hmm_try(f, size, 8, hm, path);
-    if (rc == GHMM_ERR_FORMAT) rc = hmm_try(f, size, 4, hm, path);
+    int rc = hmm_try(f, size, 8, hm, max_streams, n_streams, path);
+    if (rc == GHMM_ERR_FORMAT) rc = hmm_try(f, size, 4, hm, max_streams, n_streams, path);
     fclose(f);
     if (rc == GHMM_ERR_FORMAT)
         ghmm_set_error("%s: not a diagonal-covariance .hmm file (4- or 8-byte header)", path);
@@ -274,28 +284,52 @@ int ghmm_hmm_read(const char *path, ghmm_host_model *hm)
     return rc;
 }
 
-int ghmm_hmm_write(const char *path, const ghmm_host_model *hm, int len_bytes)
+int ghmm_hmm_read(const char *path, ghmm_host_model *hm)
 {
-    if (!path || !hm || (len_bytes != 4 && len_bytes != 8)) return GHMM_ERR_ARG;
+    if (!path || !hm) return GHMM_ERR_ARG;
+    memset(hm, 0, sizeof *hm);
+    int P = 0;
+    int rc = ghmm_hmm_read_streams(path, hm, 1, &P);
+    if (rc == GHMM_ERR_UNSUPPORTED)
+        ghmm_set_error("%s holds several feature streams: read it with ghmm_hmm_read_streams", path);
+    return rc;
+}
+
+int ghmm_hmm_write_streams(const char *path, const ghmm_host_model *hm, int n_streams, int len_bytes)
+{
+    if (!path || !hm || n_streams <= 0 || n_streams > GHMM_MAX_STREAMS || (len_bytes != 4 && len_bytes != 8))
+        return GHMM_ERR_ARG;
+    const int N = hm[0].N, P = n_streams;
+    for (int p = 1; p < P; p++)
+        if (hm[p].N != N) {
+            ghmm_set_error("ghmm_hmm_write_streams: the streams differ in their number of states");
+            return GHMM_ERR_ARG;
+        }
     FILE *f = fopen(path, "wb");
     if (!f) {
         ghmm_set_error("can't open file %s", path);
         return GHMM_ERR_IO;
     }
-    int N = hm->N, M = hm->M, D = hm->D;
-    int32_t hdr[4] = {N, 1, M, D};
-    uint64_t len = strnlen(hm->word, GHMM_MAX_WORD - 1);
+    int32_t hdr[2] = {N, P}, MD[2 * GHMM_MAX_STREAMS];
+    for (int p = 0; p < P; p++) {
+        MD[p] = hm[p].M;
+        MD[P + p] = hm[p].D;
+    }
+    uint64_t len = strnlen(hm[0].word, GHMM_MAX_WORD - 1);
     int ok = fwrite(&len, 1, (size_t)len_bytes, f) == (size_t)len_bytes; /* little-endian */
-    ok = ok && fwrite(hm->word, 1, (size_t)len, f) == (size_t)len;
-    ok = ok && fwrite(hdr, 4, 4, f) == 4;
-    ok = ok && fwrite(hm->A, 8, (size_t)N * N, f) == (size_t)N * N;
-    for (int i = 0; ok && i < N; i++) {
-        ok = fwrite(hm->c + (size_t)i * M, 8, (size_t)M, f) == (size_t)M;
-        for (int k = 0; ok && k < M; k++) {
-            size_t g = (size_t)i * M + k;
-            ok = fwrite(hm->mean + g * D, 8, (size_t)D, f) == (size_t)D &&
-                 fwrite(hm->det + g, 8, 1, f) == 1 &&
-                 fwrite(hm->inv_var + g * D, 8, (size_t)D, f) == (size_t)D;
+    ok = ok && fwrite(hm[0].word, 1, (size_t)len, f) == (size_t)len;
+    ok = ok && fwrite(hdr, 4, 2, f) == 2 && fwrite(MD, 4, 2 * (size_t)P, f) == 2 * (size_t)P;
+    ok = ok && fwrite(hm[0].A, 8, (size_t)N * N, f) == (size_t)N * N;
+    for (int p = 0; ok && p < P; p++) {
+        const int M = hm[p].M, D = hm[p].D;
+        for (int i = 0; ok && i < N; i++) {
+            ok = fwrite(hm[p].c + (size_t)i * M, 8, (size_t)M, f) == (size_t)M;
+            for (int k = 0; ok && k < M; k++) {
+                size_t g = (size_t)i * M + k;
+                ok = fwrite(hm[p].mean + g * D, 8, (size_t)D, f) == (size_t)D &&
+                     fwrite(hm[p].det + g, 8, 1, f) == 1 &&
+                     fwrite(hm[p].inv_var + g * D, 8, (size_t)D, f) == (size_t)D;
+            }
         }
     }
     if (fclose(f) != 0) ok = 0;
@@ -304,4 +338,9 @@ int ghmm_hmm_write(const char *path, const ghmm_host_model *hm, int len_bytes)
         return GHMM_ERR_IO;
     }
     return GHMM_OK;
+}
+
+int ghmm_hmm_write(const char *path, const ghmm_host_model *hm, int len_bytes)
+{
+    return ghmm_hmm_write_streams(path, hm, 1, len_bytes);
 }

@@ -151,6 +151,14 @@ k_emission(int N, int M, int D, long long F, const double *__restrict__ X,
     }
 }
 
+// several feature streams: b_i(t) <- b_i(t) * b^p_i(t), the running product of TF:1406-1409
+__global__ void __launch_bounds__(256)
+k_mul_streams(long long n, double *__restrict__ b, const double *__restrict__ bp)
+{
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256)
+        b[k] *= bp[k];
+}
+
 // ------------------------------------------------------------ group helpers
 // A "group" is L consecutive lanes (L = 16 or 64) that own one utterance, lane i =
 // state i.  Cross-lane traffic stays inside the group.

@@ -12,7 +12,9 @@
  * and the report text follow RF:374-412 and RF:1014-1194 line by line, including
  * the NaN-blind bubble sort (RF:968-995).
  *
- * One feature stream per model set (param_number = 1).
+ * A model set may have several feature streams (param_number P > 1): its P feature lists follow
+ * each other on the command line (RF:253-262) and the score runs on the product of the streams'
+ * emission densities (ghmm_score_streams, RF:349-366).
  */
 #include "ghmm.h"
 
@@ -114,14 +116,15 @@ int main(int argc, char **argv)
     strftime(date_time, sizeof date_time, "%d-%h-%Y %X", localtime(&now));
     if (argc < 7) usage();
     int K = atoi(argv[1]);
-    if (K < 1 || K > MAX_SETS || argc != 3 * K + 4) usage();
+    if (K < 1 || K > MAX_SETS || argc < 3 * K + 4) usage();
     double coef_model[MAX_SETS];
     for (int i = 0; i < K; i++) coef_model[i] = atof(argv[K + 2 + i]);
     const char *output_file = argv[argc - 1], *word_file = argv[argc - 2];
     int rc;
 
     /* models: one list per set, the same vocabulary in every set */
-    ghmm_host_model *hm[MAX_SETS];
+    ghmm_host_model *hm[MAX_SETS]; /* hm[j][k * GHMM_MAX_STREAMS + p]: set j, word k, stream p */
+    int Pj[MAX_SETS];              /* feature streams of set j (param_number of its models) */
     int word_number = 0;
     printf("\r\nLoading Models\r\n");
     for (int j = 0; j < K; j++) {
@@ -133,10 +136,17 @@ int main(int argc, char **argv)
             printf("Model: %s\r\n", name);
             if (n == cap) {
                 cap = cap ? 2 * cap : 32;
-                hm[j] = (ghmm_host_model *)realloc(hm[j], (size_t)cap * sizeof(ghmm_host_model));
+                hm[j] = (ghmm_host_model *)realloc(hm[j], (size_t)cap * GHMM_MAX_STREAMS * sizeof(ghmm_host_model));
                 if (!hm[j]) die("memory", GHMM_ERR_ALLOC);
             }
-            if ((rc = ghmm_hmm_read(name, &hm[j][n]))) die("reading model", rc);
+            int pn = 0;
+            if ((rc = ghmm_hmm_read_streams(name, &hm[j][(size_t)n * GHMM_MAX_STREAMS], GHMM_MAX_STREAMS, &pn)))
+                die("reading model", rc);
+            if (n == 0) Pj[j] = pn;
+            if (pn != Pj[j]) {
+                printf("model %s has %d parameters, the first model of %s has %d \n", name, pn, argv[2 + j], Pj[j]);
+                exit(1);
+            }
             n++;
         }
         fclose(fl);
@@ -151,18 +161,27 @@ int main(int argc, char **argv)
         exit(1);
     }
     char **word = (char **)malloc((size_t)word_number * sizeof(char *));
-    for (int k = 0; k < word_number; k++) word[k] = hm[K - 1][k].word; /* RF:229 */
+    for (int k = 0; k < word_number; k++) word[k] = hm[K - 1][(size_t)k * GHMM_MAX_STREAMS].word; /* RF:229 */
+    int n_lists = 0;
+    for (int j = 0; j < K; j++) n_lists += Pj[j];
+    if (argc != 2 * K + n_lists + 4) usage();
 
     /* spoken words and their feature files, read once */
     FILE *fw = open_read(word_file);
-    FILE *ff[MAX_SETS];
-    for (int j = 0; j < K; j++) ff[j] = open_read(argv[2 + 2 * K + j]);
+    /* one feature list per (set, stream), in command-line order (RF:253-262) */
+    FILE *ff[MAX_SETS][GHMM_MAX_STREAMS];
+    const char *ffname[MAX_SETS][GHMM_MAX_STREAMS];
+    for (int j = 0, q = 0; j < K; j++)
+        for (int p = 0; p < Pj[j]; p++, q++) {
+            ffname[j][p] = argv[2 + 2 * K + q];
+            ff[j][p] = open_read(ffname[j][p]);
+        }
     char (*spoken)[256] = NULL;
     int n_utt = 0, cap_u = 0;
-    double *X[MAX_SETS] = {0};
-    size_t frames[MAX_SETS] = {0}, capx[MAX_SETS] = {0};
+    double *X[MAX_SETS][GHMM_MAX_STREAMS] = {{0}};
+    size_t frames[MAX_SETS][GHMM_MAX_STREAMS] = {{0}}, capx[MAX_SETS][GHMM_MAX_STREAMS] = {{0}};
     int32_t *len[MAX_SETS] = {0};
-    int D[MAX_SETS] = {0};
+    int D[MAX_SETS][GHMM_MAX_STREAMS] = {{0}};
     char w[4096], path[4096];
     while (fscanf(fw, "%4095s", w) == 1) {
         if (n_utt == cap_u) {
@@ -171,33 +190,39 @@ int main(int argc, char **argv)
             for (int j = 0; j < K; j++) len[j] = (int32_t *)realloc(len[j], (size_t)cap_u * sizeof(int32_t));
         }
         snprintf(spoken[n_utt], sizeof spoken[n_utt], "%s", w);
-        for (int j = 0; j < K; j++) {
-            if (fscanf(ff[j], "%4095s", path) != 1) {
-                printf("reading error on file %s \n", argv[2 + 2 * K + j]);
-                exit(1);
+        for (int j = 0; j < K; j++)
+            for (int p = 0; p < Pj[j]; p++) {
+                if (fscanf(ff[j][p], "%4095s", path) != 1) {
+                    printf("reading error on file %s \n", ffname[j][p]);
+                    exit(1);
+                }
+                int d, T;
+                double *x;
+                if ((rc = ghmm_perfil_read(path, &d, &T, &x))) die("reading", rc);
+                if (n_utt == 0) D[j][p] = d;
+                if (d != D[j][p]) {
+                    printf("file %s has %d coefficients per frame, expected %d \n", path, d, D[j][p]);
+                    exit(1);
+                }
+                if (p == 0) len[j][n_utt] = T;
+                if (T != len[j][n_utt]) {
+                    printf("file %s has %d frames, parameter 1 of the same utterance has %d \n", path, T, len[j][n_utt]);
+                    exit(1);
+                }
+                if (frames[j][p] + (size_t)T > capx[j][p]) {
+                    capx[j][p] = (frames[j][p] + (size_t)T) * 2;
+                    X[j][p] = (double *)realloc(X[j][p], capx[j][p] * (size_t)d * sizeof(double));
+                    if (!X[j][p]) die("memory", GHMM_ERR_ALLOC);
+                }
+                memcpy(X[j][p] + frames[j][p] * (size_t)d, x, (size_t)T * (size_t)d * sizeof(double));
+                ghmm_free(x);
+                frames[j][p] += (size_t)T;
             }
-            int d, T;
-            double *x;
-            if ((rc = ghmm_perfil_read(path, &d, &T, &x))) die("reading", rc);
-            if (n_utt == 0) D[j] = d;
-            if (d != D[j]) {
-                printf("file %s has %d coefficients per frame, expected %d \n", path, d, D[j]);
-                exit(1);
-            }
-            if (frames[j] + (size_t)T > capx[j]) {
-                capx[j] = (frames[j] + (size_t)T) * 2;
-                X[j] = (double *)realloc(X[j], capx[j] * (size_t)d * sizeof(double));
-                if (!X[j]) die("memory", GHMM_ERR_ALLOC);
-            }
-            memcpy(X[j] + frames[j] * (size_t)d, x, (size_t)T * (size_t)d * sizeof(double));
-            ghmm_free(x);
-            len[j][n_utt] = T;
-            frames[j] += (size_t)T;
-        }
         n_utt++;
     }
     fclose(fw);
-    for (int j = 0; j < K; j++) fclose(ff[j]);
+    for (int j = 0; j < K; j++)
+        for (int p = 0; p < Pj[j]; p++) fclose(ff[j][p]);
 
     f_out = fopen(output_file, "w");
     if (!f_out) {
@@ -226,38 +251,49 @@ int main(int argc, char **argv)
         ghmm_ctx *ctx;
         if ((rc = ghmm_ctx_create(0, NULL, &ctx))) die("GPU context", rc);
         for (int j = 0; j < K; j++) {
-            ghmm_corpus *corpus;
-            if ((rc = ghmm_corpus_create(ctx, X[j], len[j], n_utt, D[j], &corpus))) die("corpus", rc);
-            /* the whole vocabulary in one batched call when the models share M and D
-               (ghmm_score_batch); model by model otherwise */
-            ghmm_model **dm = (ghmm_model **)calloc((size_t)word_number, sizeof(ghmm_model *));
+            const int P = Pj[j];
+            ghmm_corpus *corpus[GHMM_MAX_STREAMS];
+            for (int p = 0; p < P; p++)
+                if ((rc = ghmm_corpus_create(ctx, X[j][p], len[j], n_utt, D[j][p], &corpus[p]))) die("corpus", rc);
+            /* one stream: the whole vocabulary in one batched call when the models share M and D
+               (ghmm_score_batch), model by model otherwise; several streams: model by model on
+               the product of the streams' densities (ghmm_score_streams) */
+            ghmm_model **dm = (ghmm_model **)calloc((size_t)word_number * GHMM_MAX_STREAMS, sizeof(ghmm_model *));
             double *all = (double *)malloc((size_t)word_number * (size_t)n_utt * sizeof(double));
             if (!dm || !all) die("memory", GHMM_ERR_ALLOC);
             int same = 1;
-            for (int k = 0; k < word_number; k++) {
-                ghmm_host_model *m = &hm[j][k];
-                if (m->D != D[j]) {
-                    printf("model %s has %d coefficients, data has %d \n", m->word, m->D, D[j]);
-                    exit(1);
+            for (int k = 0; k < word_number; k++)
+                for (int p = 0; p < P; p++) {
+                    ghmm_host_model *m = &hm[j][(size_t)k * GHMM_MAX_STREAMS + p];
+                    if (m->D != D[j][p]) {
+                        printf("model %s has %d coefficients, data has %d \n", m->word, m->D, D[j][p]);
+                        exit(1);
+                    }
+                    if (m->M != hm[j][p].M) same = 0;
+                    ghmm_model **slot = &dm[(size_t)k * GHMM_MAX_STREAMS + p];
+                    if ((rc = ghmm_model_create(ctx, m->N, m->M, m->D, slot))) die("model", rc);
+                    if ((rc = ghmm_model_set(ctx, *slot, m->A, m->c, m->mean, m->inv_var, m->det))) die("model", rc);
                 }
-                if (m->M != hm[j][0].M) same = 0;
-                if ((rc = ghmm_model_create(ctx, m->N, m->M, m->D, &dm[k]))) die("model", rc);
-                if ((rc = ghmm_model_set(ctx, dm[k], m->A, m->c, m->mean, m->inv_var, m->det))) die("model", rc);
-            }
-            if (same) {
-                if ((rc = ghmm_score_batch(ctx, dm, word_number, corpus, all))) die("scoring", rc);
+            if (P == 1 && same) {
+                ghmm_model **flat = (ghmm_model **)malloc((size_t)word_number * sizeof(ghmm_model *));
+                if (!flat) die("memory", GHMM_ERR_ALLOC);
+                for (int k = 0; k < word_number; k++) flat[k] = dm[(size_t)k * GHMM_MAX_STREAMS];
+                if ((rc = ghmm_score_batch(ctx, flat, word_number, corpus[0], all))) die("scoring", rc);
+                free(flat);
             } else {
                 for (int k = 0; k < word_number; k++)
-                    if ((rc = ghmm_score(ctx, dm[k], corpus, all + (size_t)k * n_utt))) die("scoring", rc);
+                    if ((rc = ghmm_score_streams(ctx, &dm[(size_t)k * GHMM_MAX_STREAMS], corpus, P,
+                                                 all + (size_t)k * n_utt)))
+                        die("scoring", rc);
             }
             for (int k = 0; k < word_number; k++) {
                 for (int u = 0; u < n_utt; u++)
                     score[(size_t)k * n_utt + u] += coef_model[j] * all[(size_t)k * n_utt + u];
-                ghmm_model_destroy(ctx, dm[k]);
+                for (int p = 0; p < P; p++) ghmm_model_destroy(ctx, dm[(size_t)k * GHMM_MAX_STREAMS + p]);
             }
             free(dm);
             free(all);
-            ghmm_corpus_destroy(ctx, corpus);
+            for (int p = 0; p < P; p++) ghmm_corpus_destroy(ctx, corpus[p]);
         }
         ghmm_ctx_destroy(ctx);
     }
@@ -333,9 +369,10 @@ int main(int argc, char **argv)
         exit(1);
     }
     for (int j = 0; j < K; j++) {
-        for (int k = 0; k < word_number; k++) ghmm_host_model_free(&hm[j][k]);
+        for (int k = 0; k < word_number; k++)
+            for (int p = 0; p < Pj[j]; p++) ghmm_host_model_free(&hm[j][(size_t)k * GHMM_MAX_STREAMS + p]);
         free(hm[j]);
-        free(X[j]);
+        for (int p = 0; p < Pj[j]; p++) free(X[j][p]);
         free(len[j]);
     }
     free(word); free(spoken); free(score); free(part); free(index); free(wrong_word); free(probab);

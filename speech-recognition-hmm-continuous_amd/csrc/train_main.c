@@ -11,8 +11,7 @@
  *
  * Differences, on purpose:
  *   - [initial_model] works (the reference reads argv[argc], a NULL, TF:218);
- *   - param_number must be 1 (every BASELINE configuration);
- *   - no MAX_* capacity limits.
+ *   - no MAX_* capacity limits (up to GHMM_MAX_STREAMS = 8 feature streams).
  *
  * Several GPUs: start one process per GPU with
  *     GHMM_WORLD=<ranks> GHMM_RANK=<0..ranks-1> GHMM_COMM_ID=<a path unique to the job>
@@ -84,17 +83,26 @@ int main(int argc, char **argv)
     if (argc < 7) usage();
     const char *word = argv[1];
     int N = atoi(argv[2]);
-    int P = atoi(argv[3]);
-    if (P != 1) {
-        printf("param_number = %d: only one feature stream is supported \n", P);
+    const int P = atoi(argv[3]);
+    if (P < 1 || P > GHMM_MAX_STREAMS) {
+        printf("param_number = %d: between 1 and %d feature streams are supported \n", P, GHMM_MAX_STREAMS);
         exit(1);
     }
     if (argc < 2 * P + 5) usage();
-    int M = atoi(argv[4]);
-    const char *list = argv[P + 4];
+    int M[GHMM_MAX_STREAMS], D[GHMM_MAX_STREAMS];
+    const char *list[GHMM_MAX_STREAMS];
+    for (int p = 0; p < P; p++) {
+        M[p] = atoi(argv[4 + p]);
+        list[p] = argv[4 + P + p];
+        D[p] = 0;
+        if (M[p] <= 0) {
+            printf("states_number and mix_number must be positive \n");
+            exit(1);
+        }
+    }
     const char *output = argv[2 * P + 4];
     const char *initial = (argc == 2 * P + 6) ? argv[argc - 1] : NULL;
-    if (N <= 0 || M <= 0) {
+    if (N <= 0) {
         printf("states_number and mix_number must be positive \n");
         exit(1);
     }
@@ -112,27 +120,36 @@ int main(int argc, char **argv)
     }
     const int device = env_int("GHMM_DEVICE", world > 1 ? rank : 0);
 
-    /* every utterance is read once and stays resident */
-    FILE *fl = fopen(list, "r");
-    if (!fl) {
-        printf("file %s not found \n", list);
-        exit(1);
-    }
+    /* the list files: one path per utterance and stream (TF:482-502) */
     char path[4096];
-    char **files = NULL;
-    int n_files = 0, cap_f = 0, rc;
-    while (fscanf(fl, "%4095s", path) == 1) {
-        if (n_files == cap_f) {
-            cap_f = cap_f ? cap_f * 2 : 64;
-            files = (char **)realloc(files, (size_t)cap_f * sizeof(char *));
-            if (!files) die("memory", GHMM_ERR_ALLOC);
+    char **files[GHMM_MAX_STREAMS];
+    int n_files = 0, rc;
+    for (int p = 0; p < P; p++) {
+        FILE *fl = fopen(list[p], "r");
+        if (!fl) {
+            printf("file %s not found \n", list[p]);
+            exit(1);
         }
-        files[n_files] = strdup(path);
-        if (!files[n_files++]) die("memory", GHMM_ERR_ALLOC);
+        int n = 0, cap_f = 0;
+        files[p] = NULL;
+        while (fscanf(fl, "%4095s", path) == 1) {
+            if (n == cap_f) {
+                cap_f = cap_f ? cap_f * 2 : 64;
+                files[p] = (char **)realloc(files[p], (size_t)cap_f * sizeof(char *));
+                if (!files[p]) die("memory", GHMM_ERR_ALLOC);
+            }
+            files[p][n] = strdup(path);
+            if (!files[p][n++]) die("memory", GHMM_ERR_ALLOC);
+        }
+        fclose(fl);
+        if (p == 0) n_files = n;
+        if (n != n_files) {
+            printf("%s lists %d files, %s lists %d \n", list[p], n, list[0], n_files);
+            exit(1);
+        }
     }
-    fclose(fl);
     if (n_files == 0) {
-        printf("no training utterances in %s \n", list);
+        printf("no training utterances in %s \n", list[0]);
         exit(1);
     }
     /* this rank's share: all files, or the length-balanced shard (lengths from the file sizes) */
@@ -144,92 +161,113 @@ int main(int argc, char **argv)
         if (!all_len) die("memory", GHMM_ERR_ALLOC);
         for (int k = 0; k < n_files; k++) {
             int d, T;
-            if ((rc = ghmm_perfil_stat(files[k], &d, &T))) die("reading", rc);
+            if ((rc = ghmm_perfil_stat(files[0][k], &d, &T))) die("reading", rc);
             all_len[k] = T;
         }
         if ((rc = ghmm_shard_balanced(all_len, n_files, rank, world, mine, &n_mine))) die("sharding", rc);
         free(all_len);
         if (n_mine == 0) {
-            printf("rank %d of %d has no utterances (%d in %s) \n", rank, world, n_files, list);
+            printf("rank %d of %d has no utterances (%d in %s) \n", rank, world, n_files, list[0]);
             exit(1);
         }
     } else {
         for (int k = 0; k < n_files; k++) mine[k] = k;
     }
-    double *X = NULL;
-    int32_t *len = NULL;
-    size_t frames = 0, cap = 0;
-    int n_utt = 0, cap_u = 0, D = 0;
-    for (int k = 0; k < n_mine; k++) {
-        int d, T;
-        double *x;
-        snprintf(path, sizeof path, "%s", files[mine[k]]);
-        if ((rc = ghmm_perfil_read(path, &d, &T, &x))) die("reading", rc);
-        if (n_utt == 0) D = d;
-        if (d != D) {
-            printf("file %s has %d coefficients per frame, expected %d \n", path, d, D);
-            exit(1);
+    /* every utterance is read once and stays resident */
+    double *X[GHMM_MAX_STREAMS];
+    int32_t *len = (int32_t *)malloc((size_t)n_mine * sizeof(int32_t));
+    if (!len) die("memory", GHMM_ERR_ALLOC);
+    size_t frames = 0;
+    int n_utt = n_mine;
+    for (int p = 0; p < P; p++) {
+        size_t fr = 0, cap = 0;
+        X[p] = NULL;
+        for (int k = 0; k < n_mine; k++) {
+            int d, T;
+            double *x;
+            snprintf(path, sizeof path, "%s", files[p][mine[k]]);
+            if ((rc = ghmm_perfil_read(path, &d, &T, &x))) die("reading", rc);
+            if (k == 0) D[p] = d;
+            if (d != D[p]) {
+                printf("file %s has %d coefficients per frame, expected %d \n", path, d, D[p]);
+                exit(1);
+            }
+            if (p == 0) len[k] = T;
+            if (T != len[k]) {
+                printf("file %s has %d frames, parameter 1 of the same utterance has %d \n", path, T, len[k]);
+                exit(1);
+            }
+            if (fr + (size_t)T > cap) {
+                cap = (fr + (size_t)T) * 2;
+                X[p] = (double *)realloc(X[p], cap * (size_t)D[p] * sizeof(double));
+                if (!X[p]) die("memory", GHMM_ERR_ALLOC);
+            }
+            memcpy(X[p] + fr * (size_t)D[p], x, (size_t)T * (size_t)D[p] * sizeof(double));
+            ghmm_free(x);
+            fr += (size_t)T;
         }
-        if (frames + (size_t)T > cap) {
-            cap = (frames + (size_t)T) * 2;
-            X = (double *)realloc(X, cap * (size_t)D * sizeof(double));
-        }
-        if (n_utt == cap_u) {
-            cap_u = cap_u ? cap_u * 2 : 64;
-            len = (int32_t *)realloc(len, (size_t)cap_u * sizeof(int32_t));
-        }
-        if (!X || !len) die("memory", GHMM_ERR_ALLOC);
-        memcpy(X + frames * (size_t)D, x, (size_t)T * (size_t)D * sizeof(double));
-        ghmm_free(x);
-        len[n_utt++] = T;
-        frames += (size_t)T;
+        frames = fr;
+        for (int k = 0; k < n_files; k++) free(files[p][k]);
+        free(files[p]);
     }
-    for (int k = 0; k < n_files; k++) free(files[k]);
-    free(files);
     free(mine);
 
-    ghmm_host_model hm;
-    memset(&hm, 0, sizeof hm);
+    ghmm_host_model hm[GHMM_MAX_STREAMS];
+    memset(hm, 0, sizeof hm);
     ghmm_ctx *ctx;
-    ghmm_model *model;
-    ghmm_corpus *corpus;
-    ghmm_stats *stats;
+    ghmm_model *model[GHMM_MAX_STREAMS];
+    ghmm_corpus *corpus[GHMM_MAX_STREAMS];
+    ghmm_stats *stats[GHMM_MAX_STREAMS];
     ghmm_comm *comm = NULL;
     if ((rc = ghmm_ctx_create(device, NULL, &ctx))) die("GPU context", rc);
     if (comm_id && *comm_id && (rc = ghmm_comm_create_file(ctx, comm_id, rank, world, 300.0, &comm)))
         die("communicator", rc);
-    if ((rc = ghmm_corpus_create(ctx, X, len, n_utt, D, &corpus))) die("corpus", rc);
+    for (int p = 0; p < P; p++)
+        if ((rc = ghmm_corpus_create(ctx, X[p], len, n_utt, D[p], &corpus[p]))) die("corpus", rc);
     if (initial) {
-        if ((rc = ghmm_hmm_read(initial, &hm))) die("initial model", rc);
-        if (hm.D != D) {
-            printf("initial model %s has %d coefficients, data has %d \n", initial, hm.D, D);
+        int Pf = 0;
+        if ((rc = ghmm_hmm_read_streams(initial, hm, P, &Pf))) die("initial model", rc);
+        if (Pf != P) {
+            printf("initial model %s has %d parameters, the command line has %d \n", initial, Pf, P);
             exit(1);
         }
-        N = hm.N;
-        M = hm.M;
-        if ((rc = ghmm_model_create(ctx, N, M, D, &model))) die("model", rc);
-        if ((rc = ghmm_model_set(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
-    } else {
-        /* creating_initial_model (TF:226): on the GPU from the resident corpus, or with
-           GHMM_HOST_INIT=1 by the host implementation (bit-exact with the reference) */
-        if ((rc = ghmm_host_model_alloc(&hm, N, M, D))) die("memory", rc);
-        if ((rc = ghmm_model_create(ctx, N, M, D, &model))) die("model", rc);
-        const char *hi = getenv("GHMM_HOST_INIT");
-        if (hi && *hi == '1') {
-            if (world > 1) {
-                printf("GHMM_HOST_INIT=1 needs the whole corpus on one rank \n");
+        N = hm[0].N;
+        for (int p = 0; p < P; p++) {
+            if (hm[p].D != D[p]) {
+                printf("initial model %s has %d coefficients, data has %d \n", initial, hm[p].D, D[p]);
                 exit(1);
             }
-            ghmm_host_model_free(&hm);
-            if ((rc = ghmm_init_model(X, len, n_utt, N, M, D, &hm))) die("creating initial model", rc);
-            if ((rc = ghmm_model_set(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
-        } else if ((rc = ghmm_model_init_comm(ctx, model, corpus, comm))) {
-            die("creating initial model", rc);
+            M[p] = hm[p].M;
+            if ((rc = ghmm_model_create(ctx, N, M[p], D[p], &model[p]))) die("model", rc);
+            if ((rc = ghmm_model_set(ctx, model[p], hm[p].A, hm[p].c, hm[p].mean, hm[p].inv_var, hm[p].det)))
+                die("model", rc);
+        }
+    } else {
+        /* creating_initial_model (TF:226; init_mix_param once per stream, TF:814): on the GPU from the
+           resident corpus, or with GHMM_HOST_INIT=1 by the host implementation (bit-exact with the
+           reference) */
+        const char *hi = getenv("GHMM_HOST_INIT");
+        for (int p = 0; p < P; p++) {
+            if ((rc = ghmm_model_create(ctx, N, M[p], D[p], &model[p]))) die("model", rc);
+            if (hi && *hi == '1') {
+                if (world > 1) {
+                    printf("GHMM_HOST_INIT=1 needs the whole corpus on one rank \n");
+                    exit(1);
+                }
+                if ((rc = ghmm_init_model(X[p], len, n_utt, N, M[p], D[p], &hm[p]))) die("creating initial model", rc);
+                if ((rc = ghmm_model_set(ctx, model[p], hm[p].A, hm[p].c, hm[p].mean, hm[p].inv_var, hm[p].det)))
+                    die("model", rc);
+            } else {
+                if ((rc = ghmm_host_model_alloc(&hm[p], N, M[p], D[p]))) die("memory", rc);
+                if ((rc = ghmm_model_init_comm(ctx, model[p], corpus[p], comm))) die("creating initial model", rc);
+            }
         }
     }
-    snprintf(hm.word, sizeof hm.word, "%s", word);
-    if ((rc = ghmm_stats_create(ctx, N, M, D, &stats))) die("statistics", rc);
-    size_t ns = ghmm_stats_len(N, M, D);
+    for (int p = 0; p < P; p++) {
+        snprintf(hm[p].word, sizeof hm[p].word, "%s", word);
+        if ((rc = ghmm_stats_create(ctx, N, M[p], D[p], &stats[p]))) die("statistics", rc);
+    }
+    size_t ns = ghmm_stats_len(N, M[0], D[0]);
     double *sv = (double *)malloc(ns * sizeof(double));
     if (!sv) die("memory", GHMM_ERR_ALLOC);
 
@@ -239,10 +277,11 @@ int main(int argc, char **argv)
     do {
         iteration++;
         printf("\r\nStarting training sequence (%d utterances, %zu frames)", n_utt, frames);
-        if ((rc = ghmm_estep(ctx, model, corpus, stats))) die("E-step", rc);
-        /* the one exchange of the iteration: sum of the accumulators over ranks */
-        if (comm && (rc = ghmm_stats_allreduce(ctx, stats, comm))) die("all-reduce", rc);
-        if ((rc = ghmm_stats_download(ctx, stats, sv))) die("E-step", rc);
+        if ((rc = ghmm_estep_streams(ctx, model, corpus, P, stats))) die("E-step", rc);
+        /* the one exchange of the iteration: sum of the accumulators over ranks (one vector per stream) */
+        for (int p = 0; comm && p < P; p++)
+            if ((rc = ghmm_stats_allreduce(ctx, stats[p], comm))) die("all-reduce", rc);
+        if ((rc = ghmm_stats_download(ctx, stats[0], sv))) die("E-step", rc);
         probab = sv[ns - 2];
         printf("\r\nEnding training sequence");
         variation = fabs((old_probab - probab) / old_probab);
@@ -250,14 +289,17 @@ int main(int argc, char **argv)
         if (variation > THRESHOLD) {
             /* the statistics of the converging pass are discarded (TF:328) */
             old_probab = probab;
-            if ((rc = ghmm_mstep(ctx, model, stats))) die("M-step", rc);
+            for (int p = 0; p < P; p++)
+                if ((rc = ghmm_mstep(ctx, model[p], stats[p]))) die("M-step", rc);
         }
     } while (variation > THRESHOLD);
     printf("\r\nFinal Probability = %f\r\n\r\n", variation);
     if (comm) n_utt = (int)sv[ns - 1]; /* exemplars of all ranks (TF:320, summed) */
     probab /= (double)n_utt;
 
-    if ((rc = ghmm_model_get(ctx, model, hm.A, hm.c, hm.mean, hm.inv_var, hm.det))) die("model", rc);
+    for (int p = 0; p < P; p++)
+        if ((rc = ghmm_model_get(ctx, model[p], hm[p].A, hm[p].c, hm[p].mean, hm[p].inv_var, hm[p].det)))
+            die("model", rc);
 
     /* cpu time exactly as the reference formats it (TF:364-369; its /60 assumes 60 ticks/s) */
     struct tms tm_cpu;
@@ -270,7 +312,7 @@ int main(int argc, char **argv)
     strftime(t_end, sizeof t_end, "%d-%h-%Y %X", localtime(&now));
 
     if (rank != 0) goto done; /* every rank holds the same model; rank 0 writes it */
-    if ((rc = ghmm_hmm_write(output, &hm, 8))) die("writing model", rc);
+    if ((rc = ghmm_hmm_write_streams(output, hm, P, 8))) die("writing model", rc);
 
     FILE *ft = fopen(text_file, "w");
     if (!ft) {
@@ -283,8 +325,8 @@ int main(int argc, char **argv)
     fprintf(ft, "word: %s \n", word);
     fprintf(ft, "number of states: %d \n", N);
     fprintf(ft, "number of parameters: %d \n", P);
-    fprintf(ft, "number of mixtures %d: %d \n", 1, M);
-    fprintf(ft, "parameter %d: %s \n", 1, list);
+    for (int p = 0; p < P; p++) fprintf(ft, "number of mixtures %d: %d \n", p + 1, M[p]);
+    for (int p = 0; p < P; p++) fprintf(ft, "parameter %d: %s \n", p + 1, list[p]);
     fprintf(ft, "threshould to finish training: %f \n", THRESHOLD);
     fprintf(ft, "number of exemplars in training sequence: %d \n", n_utt);
     fprintf(ft, "mean probability: %f \n", probab);
@@ -299,13 +341,15 @@ int main(int argc, char **argv)
 
 done:
     ghmm_comm_destroy(comm);
-    ghmm_stats_destroy(ctx, stats);
-    ghmm_corpus_destroy(ctx, corpus);
-    ghmm_model_destroy(ctx, model);
+    for (int p = 0; p < P; p++) {
+        ghmm_stats_destroy(ctx, stats[p]);
+        ghmm_corpus_destroy(ctx, corpus[p]);
+        ghmm_model_destroy(ctx, model[p]);
+        ghmm_host_model_free(&hm[p]);
+        free(X[p]);
+    }
     ghmm_ctx_destroy(ctx);
-    ghmm_host_model_free(&hm);
     free(sv);
-    free(X);
     free(len);
     return 0;
 }

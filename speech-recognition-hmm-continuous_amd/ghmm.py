@@ -92,6 +92,8 @@ SYMBOLS = {
     "ghmm_mstep": (C.c_int, [_vp, _vp, _vp], True),
     "ghmm_score": (C.c_int, [_vp, _vp, _vp, _dp], True),
     "ghmm_score_batch": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, _dp], True),
+    "ghmm_estep_streams": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_int, C.POINTER(_vp)], True),
+    "ghmm_score_streams": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_int, _dp], True),
     "ghmm_viterbi": (C.c_int, [_vp, _vp, _vp, _ip, _dp], True),
     "ghmm_perfil_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(_dp)], False),
@@ -105,6 +107,10 @@ SYMBOLS = {
     "ghmm_host_model_free": (None, [C.POINTER(HostModelStruct)], False),
     "ghmm_hmm_read": (C.c_int, [C.c_char_p, C.POINTER(HostModelStruct)], False),
     "ghmm_hmm_write": (C.c_int, [C.c_char_p, C.POINTER(HostModelStruct), C.c_int], False),
+    "ghmm_hmm_read_streams": (C.c_int, [C.c_char_p, C.POINTER(HostModelStruct), C.c_int,
+                                        C.POINTER(C.c_int)], False),
+    "ghmm_hmm_write_streams": (C.c_int, [C.c_char_p, C.POINTER(HostModelStruct), C.c_int, C.c_int],
+                               False),
     "ghmm_init_model": (C.c_int, [_dp, _ip, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(HostModelStruct)], False),
     "ghmm_synth_truth": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, _dp, _dp], False),
@@ -215,6 +221,21 @@ class HostModel:
         lib = host_lib()
         s = self._struct()
         _check(lib.ghmm_hmm_write(os.fsencode(path), C.byref(s), len_bytes), lib)
+
+    @staticmethod
+    def read_streams(path, max_streams=8):
+        """A model of several feature streams (param_number P): one HostModel per stream."""
+        lib = host_lib()
+        arr = (HostModelStruct * max_streams)()
+        n = C.c_int()
+        _check(lib.ghmm_hmm_read_streams(os.fsencode(path), arr, max_streams, C.byref(n)), lib)
+        return [HostModel._from_struct(arr[p], lib) for p in range(n.value)]
+
+    @staticmethod
+    def write_streams(path, hms, len_bytes=8):
+        lib = host_lib()
+        arr = (HostModelStruct * len(hms))(*[h._struct() for h in hms])
+        _check(lib.ghmm_hmm_write_streams(os.fsencode(path), arr, len(hms), len_bytes), lib)
 
     @staticmethod
     def init_from(X, lens, N, M):
@@ -409,6 +430,22 @@ class Context:
         arr = (_vp * len(models))(*[m.h for m in models])
         out = np.empty((len(models), corpus.n_utt), dtype=np.float64)
         _check(self.lib.ghmm_score_batch(self.h, arr, len(models), corpus.h, _d(out)), self.lib)
+        return out
+
+    # ---- several feature streams (param_number P > 1)
+    def estep_streams(self, models, corpora, stats):
+        P = len(models)
+        pm = (_vp * P)(*[m.h for m in models])
+        pc = (_vp * P)(*[c.h for c in corpora])
+        ps = (_vp * P)(*[s.h for s in stats])
+        _check(self.lib.ghmm_estep_streams(self.h, pm, pc, P, ps), self.lib)
+
+    def score_streams(self, models, corpora):
+        P = len(models)
+        pm = (_vp * P)(*[m.h for m in models])
+        pc = (_vp * P)(*[c.h for c in corpora])
+        out = np.empty(corpora[0].n_utt, dtype=np.float64)
+        _check(self.lib.ghmm_score_streams(self.h, pm, pc, P, _d(out)), self.lib)
         return out
 
     def viterbi(self, model, corpus):

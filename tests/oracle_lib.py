@@ -40,6 +40,15 @@ def lib():
         L.orc_log_emission.argtypes = [C.c_int] * 4 + [_dp] * 6
         L.orc_emission.restype = None
         L.orc_emission.argtypes = [C.c_int] * 4 + [_dp] * 7
+        _pp = C.POINTER(_dp)
+        L.orc_estep_streams.restype = C.c_int
+        L.orc_estep_streams.argtypes = ([C.c_int, C.c_int, _ip, _ip, C.c_int, _dp] + [_pp] * 5 +
+                                        [_ip, C.c_int, _pp, _dp, _dp])
+        L.orc_train_streams.restype = C.c_int
+        L.orc_train_streams.argtypes = ([C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_double, C.c_int, C.c_int,
+                                         _dp] + [_pp] * 5 + [_ip, C.c_int, _dp, _dp])
+        L.orc_score_streams.restype = C.c_double
+        L.orc_score_streams.argtypes = [C.c_int, C.c_int, _ip, _ip, C.c_int, _dp] + [_pp] * 5
         L.orc_sort_scores.restype = None
         L.orc_sort_scores.argtypes = [C.c_int, _dp, _ip]
         _lib = L
@@ -143,3 +152,60 @@ def sort_scores(scores):
     idx = np.zeros(len(scores), dtype=np.int32)
     lib().orc_sort_scores(len(scores), _d(scores), idx.ctypes.data_as(_ip))
     return idx
+
+
+# ---------------------------------------------------------- several feature streams
+
+def _ptrs(arrays):
+    """C array of double* over numpy arrays (kept alive by the caller)."""
+    return (_dp * len(arrays))(*[_d(a) for a in arrays])
+
+
+def _stream_args(hms, Xs):
+    P = len(hms)
+    M = np.array([h.M for h in hms], dtype=np.int32)
+    D = np.array([h.D for h in hms], dtype=np.int32)
+    Xs = [np.ascontiguousarray(x, dtype=np.float64) for x in Xs]
+    return P, M, D, Xs
+
+
+def estep_streams(hms, Xs, lens, delta=1):
+    """E-step of a P-stream model (hms[p] = stream p as a HostModel, A from hms[0]), TF:272-321
+    with param_number = P.  Returns ([stats_p], product b[F][N], loglik[U])."""
+    P, M, D, Xs = _stream_args(hms, Xs)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    N, F, U = hms[0].N, int(lens.sum()), len(lens)
+    stats = [np.zeros(stats_len(N, h.M, h.D)) for h in hms]
+    b, ll = np.zeros((F, N)), np.zeros(U)
+    rc = lib().orc_estep_streams(P, N, M.ctypes.data_as(_ip), D.ctypes.data_as(_ip), delta, _d(hms[0].A),
+                                 _ptrs([h.c for h in hms]), _ptrs([h.mean for h in hms]),
+                                 _ptrs([h.inv_var for h in hms]), _ptrs([h.det for h in hms]),
+                                 _ptrs(Xs), lens.ctypes.data_as(_ip), U, _ptrs(stats), _d(b), _d(ll))
+    assert rc == 0
+    return stats, b, ll
+
+
+def train_streams(hms, Xs, lens, delta=1, threshold=1e-3, max_iter=0, fixed_iter=False):
+    """EM driver for P streams.  Returns ([new HostModel per stream], iterations, mean loglik)."""
+    P, M, D, Xs = _stream_args(hms, Xs)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    new = [h.copy() for h in hms]
+    A = new[0].A
+    mean_ll = C.c_double()
+    it = lib().orc_train_streams(P, hms[0].N, M.ctypes.data_as(_ip), D.ctypes.data_as(_ip), delta,
+                                 threshold, max_iter, int(fixed_iter), _d(A),
+                                 _ptrs([h.c for h in new]), _ptrs([h.mean for h in new]),
+                                 _ptrs([h.inv_var for h in new]), _ptrs([h.det for h in new]),
+                                 _ptrs(Xs), lens.ctypes.data_as(_ip), len(lens), C.byref(mean_ll), None)
+    assert it > 0
+    for h in new[1:]:
+        h.A[:] = A
+    return new, it, mean_ll.value
+
+
+def score_streams(hms, Xs):
+    P, M, D, Xs = _stream_args(hms, Xs)
+    return lib().orc_score_streams(P, hms[0].N, M.ctypes.data_as(_ip), D.ctypes.data_as(_ip),
+                                   Xs[0].shape[0], _d(hms[0].A), _ptrs([h.c for h in hms]),
+                                   _ptrs([h.mean for h in hms]), _ptrs([h.inv_var for h in hms]),
+                                   _ptrs([h.det for h in hms]), _ptrs(Xs))

@@ -1155,3 +1155,139 @@ def test_config5_full_size_properties(G, ctx):
         assert_frames(bfull, ref, f"config 5 full run, frames {f0}..")
         c.close()
     model.close()
+
+
+# ------------------------------------------------ several feature streams (param_number P > 1)
+
+@pytest.fixture(scope="module")
+def streams():
+    return json.load(open(os.path.join(GOLDEN, "streams_p2.json")))
+
+
+def _stream_data(G, streams, idx):
+    from streams_util import second_stream
+    Xs = [G.perfil_read(os.path.join(GOLDEN, "perfil", streams["mean_list"][k])) for k in idx]
+    lens = np.array([len(x) for x in Xs], dtype=np.int32)
+    return [np.concatenate(Xs), np.concatenate([second_stream(x, streams["D2"]) for x in Xs])], lens
+
+
+def _golden_streams(G, rec, word=""):
+    m = rec["model"]
+    return [G.HostModel(m["A"], s["c"], s["mean"], s["inv_var"], s["det"], word=word) for s in m["streams"]]
+
+
+def _estep_streams_vs_oracle(G, ctx, hms, Xs, lens, tag):
+    models = [ctx.model(h) for h in hms]
+    corpora = [ctx.corpus(x, lens) for x in Xs]
+    stats = [ctx.stats(h.N, h.M, h.D) for h in hms]
+    ctx.estep_streams(models, corpora, stats)
+    ref_stats, ref_b, ref_ll = O.estep_streams(hms, Xs, lens)
+    F, N = int(np.sum(lens)), hms[0].N
+    assert_frames(ctx.fetch(G.BUF_B, (F, N)), ref_b, tag + " product b")
+    assert_close(ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ref_ll, what=tag + " loglik")
+    for p, (s, r) in enumerate(zip(stats, ref_stats)):
+        got, ref = G.split_stats(s.download(), N, hms[p].M, hms[p].D), G.split_stats(r, N, hms[p].M, hms[p].D)
+        for k in ref:
+            assert_close(got[k], ref[k], what=f"{tag} stream {p} stats.{k}")
+    # M-step per stream (TF:332-346): every stream's call writes the same A
+    for p in range(len(hms)):
+        ctx.mstep(models[p], stats[p])
+        new, ref_new = models[p].get(), O.mstep(hms[p], ref_stats[p])
+        for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), new.arrays(), ref_new.arrays()):
+            assert_close(a, b, rtol=1e-7, what=f"{tag} stream {p} mstep.{nm}")
+    assert_close(ctx.score_streams(models, corpora),
+                 [O.score_streams([m.get() for m in models], [x[o:o + t] for x in Xs])
+                  for o, t in zip(np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)],
+                 rtol=1e-9, what=tag + " score after the M-step")
+    for o in models + corpora + stats:
+        o.close()
+
+
+def test_streams_estep_against_oracle(G, ctx, streams):
+    """Two feature streams on the bundled utterances (9-d + 5-d, 3 + 2 mixtures: the vector-ALU
+    and generic kernels) and on synthetic 39-d + 13-d streams with 8 + 4 mixtures (the matrix-core
+    kernels): product b, log P, every stream's statistics and M-step against the oracle, which
+    reproduces the real two-stream trainer bit for bit (tests/test_oracle.py)."""
+    Xs, lens = _stream_data(G, streams, range(13))
+    _estep_streams_vs_oracle(G, ctx, _golden_streams(G, streams["train_all13_p2"]), Xs, lens, "bundled")
+    hm1, X1, lens = synth_case(G, 10, 8, 39, [120, 77, 64, 90, 33])
+    hm2, X2, _ = synth_case(G, 10, 4, 13, [120, 77, 64, 90, 33], first=50)
+    hm2.A[:] = hm1.A
+    _estep_streams_vs_oracle(G, ctx, [hm1, hm2], [X1, X2], lens, "synthetic")
+
+
+def test_streams_training_matches_reference_program(G, ctx, streams):
+    """The EM loop over two streams on the GPU from the reference-identical initial models: the
+    real trainer's iteration count, printed mean log-likelihood and written model."""
+    exp = streams["train_all13_p2"]
+    Xs, lens = _stream_data(G, streams, range(13))
+    hms = [G.HostModel.init_from(Xs[p], lens, 6, exp["model"]["M"][p]) for p in range(2)]
+    models = [ctx.model(h) for h in hms]
+    corpora = [ctx.corpus(x, lens) for x in Xs]
+    stats = [ctx.stats(h.N, h.M, h.D) for h in hms]
+    old, it = 1.0, 0
+    while True:
+        it += 1
+        ctx.estep_streams(models, corpora, stats)
+        p = float(stats[0].download()[-2])
+        var = abs((old - p) / old)
+        if not var > 1e-3 or it > 100:
+            break
+        old = p
+        for m, s in zip(models, stats):
+            ctx.mstep(m, s)
+    assert it == exp["iterations"]
+    assert p / len(lens) == pytest.approx(exp["mean_probability"], rel=1e-9, abs=1e-6)
+    for got, ref in zip(models, _golden_streams(G, exp)):
+        for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), got.get().arrays(), ref.arrays()):
+            assert_close(a, b, rtol=1e-6, what="all13 P=2 " + nm)
+    for o in models + corpora + stats:
+        o.close()
+
+
+def test_streams_command_lines(G, streams, tmp_path):
+    """Both executables with param_number = 2 (argv as the reference takes it: the mixtures, then
+    the lists, stream by stream): the trainer's report and model against the real trainer's, the
+    recogniser's report line for line against the real recogniser's."""
+    from streams_util import second_stream
+    tmp = str(tmp_path)
+    s1, s2 = [], []
+    for fn in streams["mean_list"]:
+        X = G.perfil_read(os.path.join(GOLDEN, "perfil", fn))
+        p2 = os.path.join(tmp, "d_" + fn)
+        G.perfil_write(p2, second_stream(X, streams["D2"]))
+        s1.append(os.path.join(GOLDEN, "perfil", fn))
+        s2.append(p2)
+    l1, l2 = _write_lists(tmp, s1, "list1.txt"), _write_lists(tmp, s2, "list2.txt")
+    exe = os.path.join(PKG_DIR, "bin", "hmm-continuous-train-fs")
+    out = os.path.join(tmp, "all13p2.hmm")
+    p = subprocess.run([exe, "all13p2", "6", "2", "3", "2", l1, l2, out], stdout=subprocess.PIPE,
+                       env={**os.environ, "GHMM_HOST_INIT": "1"})
+    assert p.returncode == 0, p.stdout.decode()
+    exp = streams["train_all13_p2"]
+    rep = open(out[:-4] + ".txt").read().split("\n")
+    assert rep[4] == "number of parameters: 2 "
+    assert rep[5:9] == ["number of mixtures 1: 3 ", "number of mixtures 2: 2 ", f"parameter 1: {l1} ",
+                        f"parameter 2: {l2} "]
+    assert rep[11] == f"mean probability: {exp['mean_probability']:f} "
+    assert rep[12] == f"number of iterations: {exp['iterations']} "
+    got = G.HostModel.read_streams(out)
+    assert [h.word for h in got] == ["all13p2"] * 2
+    for g, r in zip(got, _golden_streams(G, exp)):
+        for nm, a, b in zip(("A", "c", "mean", "inv_var", "det"), g.arrays(), r.arrays()):
+            assert_close(a, b, rtol=1e-6, what="trainer P=2 " + nm)
+    # the recogniser on the real trainer's 13 two-stream word models
+    paths = []
+    for w in streams["words"]:
+        paths.append(os.path.join(tmp, w + ".hmm"))
+        G.HostModel.write_streams(paths[-1], _golden_streams(G, streams["train13_p2"][w], word=w))
+    ml = _write_lists(tmp, paths, "models.txt")
+    wl = _write_lists(tmp, streams["words"], "words.txt")
+    exe = os.path.join(PKG_DIR, "bin", "recognition-continuous-test-fs")
+    rout = os.path.join(tmp, "report.txt")
+    p = subprocess.run([exe, "1", ml, "1", l1, l2, wl, rout], stdout=subprocess.PIPE)
+    assert p.returncode == 0, p.stdout.decode()
+    got = [l for l in open(rout).read().split("\n")
+           if not l.startswith("Date and time") and "recognition time" not in l
+           and not l.startswith("Model name")]
+    assert got == streams["recog13_p2"]["report"]

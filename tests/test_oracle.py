@@ -137,3 +137,62 @@ def test_log_emission_consistent_with_linear(load_case):
     c = load_case("synth39_m8")
     lb = O.log_emission(c.model0, c.X)
     assert np.allclose(lb, np.log(c.frames("b")), rtol=1e-12, atol=0)
+
+
+# ------------------------------------------------------------- several feature streams
+
+@pytest.fixture(scope="module")
+def streams():
+    return json.load(open(os.path.join(GOLDEN, "streams_p2.json")))
+
+
+def stream_data(G, streams, idx):
+    """The two streams of the bundled utterances `idx`: the 9-d frames and their 5-d
+    differences (tests/streams_util.py — what make_golden_streams.py fed the real reference)."""
+    from streams_util import second_stream
+    Xs = [G.perfil_read(os.path.join(GOLDEN, "perfil", streams["mean_list"][k])) for k in idx]
+    lens = [len(x) for x in Xs]
+    return [np.concatenate(Xs), np.concatenate([second_stream(x, streams["D2"]) for x in Xs])], lens
+
+
+def golden_stream_models(G, rec):
+    m = rec["model"]
+    return [G.HostModel(m["A"], s["c"], s["mean"], s["inv_var"], s["det"]) for s in m["streams"]]
+
+
+def test_oracle_streams_match_the_reference_trainer(G, streams):
+    """param_number = 2 (TF:1406-1409, 1501-1504, 1607-1610; calc_symbol_probab / calc_mix_param per
+    stream TF:278-315): the real trainer's iteration count, printed mean log-likelihood and every
+    double of the model it wrote, from the reference-identical initial model of each stream."""
+    exp = streams["train_all13_p2"]
+    Xs, lens = stream_data(G, streams, range(13))
+    hm0 = [G.HostModel.init_from(Xs[p], lens, 6, exp["model"]["M"][p]) for p in range(2)]
+    new, it, mp = O.train_streams(hm0, Xs, lens)
+    assert it == exp["iterations"]
+    assert f"{mp:f}" == f"{exp['mean_probability']:f}"
+    for got, ref in zip(new, golden_stream_models(G, exp)):
+        for a, b in zip(got.arrays(), ref.arrays()):
+            assert np.array_equal(a, b.reshape(a.shape))
+    by_word = {fn[5:-7]: k for k, fn in enumerate(streams["mean_list"])}
+    for w in streams["words"][:4]:
+        exp = streams["train13_p2"][w]
+        Xw, lw = stream_data(G, streams, [by_word[w]])
+        new, it, mp = O.train_streams([G.HostModel.init_from(Xw[p], lw, 6, 1) for p in range(2)], Xw, lw)
+        assert it == exp["iterations"] and f"{mp:f}" == f"{exp['mean_probability']:f}", w
+        for got, ref in zip(new, golden_stream_models(G, exp)):
+            for a, b in zip(got.arrays(), ref.arrays()):
+                assert np.array_equal(a, b.reshape(a.shape)), w
+
+
+def test_oracle_streams_match_the_reference_recogniser(G, streams):
+    """RF:349-366 with two streams: the recogniser's printed scores of 13 utterances x 13
+    two-stream models, -inf / nan artefacts included, and its NaN-blind ranking."""
+    words = streams["words"]
+    models = [golden_stream_models(G, streams["train13_p2"][w]) for w in words]
+    for u, blk in enumerate(streams["recog13_p2"]["blocks"]):
+        Xu, _ = stream_data(G, streams, [u])
+        scores = np.array([O.score_streams(m, Xu) for m in models])
+        order = O.sort_scores(scores)
+        assert [words[i] for i in order] == [w for w, _ in blk["ranking"]], blk["spoken"]
+        for i, (w, txt) in zip(order, blk["ranking"]):
+            assert cfmt(scores[i]).lstrip("-") == txt.lstrip("-") or cfmt(scores[i]) == txt, (blk["spoken"], w)
