@@ -1152,9 +1152,18 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         constexpr int NXL = NE, NPL = 2 * CT, NGL = 2;
         const int nxp = 8 * D, npp = 8 * GW, ngp = 8 * N, ppr = GW / 2;
         const float rD = 1.0f / (float)D, rppr = 1.0f / (float)ppr;
-        v2d rx[NXL], rp[NPL], rg[NGL];
+        // gamma is EXACTLY 0 for most (frame, state) pairs (alpha^ beta^ underflows away from the
+        // path: 87 % at BASELINE configs[1]), and a weight of 0 adds exactly nothing.  Per stage the
+        // states with a non-zero gamma anywhere in its 16 frames form a bit mask (gamma travels one
+        // stage ahead of the posteriors for that); posterior pieces of the other states are not
+        // fetched (their loads are pointed at the stage's first piece: no branch, no HBM traffic,
+        // whatever they bring is multiplied by 0) and a Gaussian tile none of whose states is in
+        // the mask skips its LDS reads and MFMAs.
+        v2d rx[NXL], rp[NPL], rg[NGL], rgn[NGL];
         unsigned offp[NPL]; // posterior piece -> element offset inside a stage (rows strided by G)
         unsigned pcp[NPL], pcx[NXL], pcg[NGL]; // clamped piece indices
+        unsigned pst[NPL];                     // state of the piece's two Gaussians (M even)
+        unsigned gb0[NGL], gb1[NGL];           // state bits of the two gammas of a piece
 #pragma unroll
         for (int u = 0; u < NPL; u++) {
             int pc = l + 64 * u;
@@ -1163,12 +1172,33 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             int row, c2;
             divmod_small(pc, ppr, rppr, row, c2);
             offp[u] = (unsigned)(row * G + gmin + 2 * c2);
+            pst[u] = (unsigned)((gmin + 2 * c2) / M);
         }
 #pragma unroll
         for (int u = 0; u < NGL; u++) {
             const int pc = l + 64 * u;
             pcg[u] = (unsigned)(pc < ngp ? pc : ngp - 1);
+            gb0[u] = 1u << ((2 * pcg[u]) % (unsigned)N);
+            gb1[u] = 1u << ((2 * pcg[u] + 1) % (unsigned)N);
         }
+        // states covered by Gaussian tile c of this chunk
+        unsigned tm[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const int g_lo = (c0 + c) * 16, g_hi = g_lo + 15;
+            const int s_lo = g_lo / Mp, s_hi = g_hi / Mp < N ? g_hi / Mp : N - 1;
+            tm[c] = (c0 + c < NT && s_lo < N) ? ((2u << s_hi) - 1u) & ~((1u << s_lo) - 1u) : 0u;
+        }
+        // bit i = some frame of the stage whose gammas sit in `q` has gamma(state i) != 0
+        auto state_mask = [&](const v2d (&q)[NGL]) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int u = 0; u < NGL; u++)
+                bits |= (q[u][0] != 0.0 ? gb0[u] : 0u) | (q[u][1] != 0.0 ? gb1[u] : 0u);
+            unsigned m = 0;
+            for (int i = 0; i < N; i++) m |= (__ballot((bits >> i) & 1u) != 0ull ? 1u : 0u) << i;
+            return m;
+        };
         // where the two doubles of X piece u land: (slab offset << 8) | coefficient index
         unsigned xa[NXL], xb[NXL];
 #pragma unroll
@@ -1183,19 +1213,31 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             xa[u] = ((unsigned)(r0 * XS + d0) << 8) | (unsigned)d0;
             xb[u] = ((unsigned)(r1 * XS + d1) << 8) | (unsigned)d1;
         }
-        auto fetch = [&](long long stg) {
+        auto fetch_gamma = [&](long long stg, v2d (&q)[NGL]) {
+            const v2d *gsrc = (const v2d *)(gamma + uniform64(stg * 16 * N));
+#pragma unroll
+            for (int u = 0; u < NGL; u++) q[u] = gsrc[pcg[u]];
+        };
+        // frames and the posteriors of the states in `smask` (the others: the stage's first piece)
+        auto fetch = [&](long long stg, unsigned smask) {
             const long long f = stg * 16;
             const v2d *xsrc = (const v2d *)(X + uniform64(f * D));
-            const v2d *gsrc = (const v2d *)(gamma + uniform64(f * N));
-            const double *psrc = post + uniform64(f * G);
+            const double *psrc = post + uniform64(f * G + gmin);
 #pragma unroll
             for (int u = 0; u < NXL; u++) rx[u] = xsrc[pcx[u]];
 #pragma unroll
-            for (int u = 0; u < NPL; u++) rp[u] = *(const v2d *)(psrc + offp[u]);
-#pragma unroll
-            for (int u = 0; u < NGL; u++) rg[u] = gsrc[pcg[u]];
+            for (int u = 0; u < NPL; u++) {
+                const unsigned o = ((smask >> pst[u]) & 1u) ? offp[u] - (unsigned)gmin : 0u;
+                rp[u] = *(const v2d *)(psrc + o);
+            }
         };
-        if (s0 < s1) fetch(s0);
+        unsigned smask_cur = 0;
+        if (s0 < s1) {
+            fetch_gamma(s0, rg);
+            fetch_gamma(s0 + 1 < s1 ? s0 + 1 : s0, rgn);
+            smask_cur = state_mask(rg);
+            fetch(s0, smask_cur);
+        }
         if (l < DP) ol[l] = og_l;
         if (l + WAVE < DP) ol[l + WAVE] = og_h;
         for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
@@ -1215,7 +1257,17 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
 #pragma unroll
             for (int u = 0; u < NGL; u++) ((v2d *)gs)[pcg[u]] = rg[u];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
-            fetch(stg + 1 < s1 ? stg + 1 : stg); // in flight under this stage's MFMAs
+            // the next stage, in flight under this stage's MFMAs: its gammas arrived a stage ago
+            const unsigned smask_next = state_mask(rgn);
+            fetch(stg + 1 < s1 ? stg + 1 : stg, smask_next);
+#pragma unroll
+            for (int u = 0; u < NGL; u++) rg[u] = rgn[u];
+            fetch_gamma(stg + 2 < s1 ? stg + 2 : (stg + 1 < s1 ? stg + 1 : stg), rgn);
+            // Gaussian tiles with a state of this stage's mask
+            unsigned tact = 0;
+#pragma unroll
+            for (int c = 0; c < CT; c++) tact |= ((smask_cur & tm[c]) != 0u ? 1u : 0u) << c;
+            smask_cur = smask_next;
             // four k-steps per stage, two per iteration of a rolled loop (unrolling all four
             // makes hipcc shuffle the accumulators between AGPRs and VGPRs).  Two operand
             // sets alternate: the operands of the next step are read from LDS before the
@@ -1232,23 +1284,25 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             auto rd = [&](int q, double (&g)[CT], double (&p)[CT], double (&f)[NE]) {
                 const int og = 4 * q * N, op = 4 * q * GW, of = 4 * q * XS; // wave-uniform
 #pragma unroll
-                for (int c = 0; c < CT; c++) {
-                    g[c] = gsl[c][og];
-                    p[c] = psl[c][op];
-                }
+                for (int c = 0; c < CT; c++)
+                    if ((tact >> c) & 1u) {
+                        g[c] = gsl[c][og];
+                        p[c] = psl[c][op];
+                    }
 #pragma unroll
                 for (int n = 0; n < NE; n++) f[n] = fxl[of + 16 * n];
             };
             auto run = [&](const double (&g)[CT], const double (&p)[CT], const double (&f)[NE]) {
-                double wv[CT];
-#pragma unroll
-                for (int c = 0; c < CT; c++) wv[c] = g[c] * p[c] * mk[c];
 #pragma unroll
                 for (int c = 0; c < CT; c++)
+                    if ((tact >> c) & 1u) {
+                        const double wv = g[c] * p[c] * mk[c];
 #pragma unroll
-                    for (int n = 0; n < NE; n++)
-                        acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[c], f[n], acc[c][n], 0, 0, 0);
+                        for (int n = 0; n < NE; n++)
+                            acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, f[n], acc[c][n], 0, 0, 0);
+                    }
             };
+            if (tact == 0) continue; // nobody occupies any state of this chunk in these 16 frames
             rd(0, gA, pA, fA);
 #pragma unroll 1
             for (int h = 0; h < 2; h++) {
