@@ -314,6 +314,57 @@ int orc_estep(int N, int M, int D, int delta, const double *A, const double *c,
     return 0;
 }
 
+/* The same E-step with the utterances dealt to `threads` host threads in contiguous blocks and
+ * the threads' accumulator vectors added in thread order (the optional all-core CPU
+ * figure beside the single-thread one; the reference itself is single-threaded).  No per-frame
+ * dumps.  Returns 0, or 1 on failure. */
+#include <pthread.h>
+struct orc_mt_job {
+    int N, M, D, delta, n_utt, rc;
+    const double *A, *c, *mean, *inv_var, *det, *X;
+    const int32_t *len;
+    double *stats;
+};
+static void *orc_mt_run(void *arg)
+{
+    struct orc_mt_job *j = (struct orc_mt_job *)arg;
+    j->rc = orc_estep(j->N, j->M, j->D, j->delta, j->A, j->c, j->mean, j->inv_var, j->det, j->X, j->len,
+                      j->n_utt, j->stats, NULL, NULL, NULL, NULL, NULL, NULL);
+    return NULL;
+}
+int orc_estep_mt(int threads, int N, int M, int D, int delta, const double *A, const double *c,
+                 const double *mean, const double *inv_var, const double *det, const double *X,
+                 const int32_t *len, int n_utt, double *stats)
+{
+    if (threads < 1) threads = 1;
+    if (threads > n_utt) threads = n_utt > 0 ? n_utt : 1;
+    size_t ns = orc_stats_len(N, M, D);
+    struct orc_mt_job *jobs = calloc((size_t)threads, sizeof *jobs);
+    pthread_t *tid = calloc((size_t)threads, sizeof *tid);
+    double *all = calloc((size_t)threads * ns, sizeof(double));
+    if (!jobs || !tid || !all) return 1;
+    size_t f0 = 0;
+    int u0 = 0, bad = 0;
+    for (int t = 0; t < threads; t++) {
+        int u1 = (int)((long long)n_utt * (t + 1) / threads);
+        struct orc_mt_job *j = &jobs[t];
+        j->N = N; j->M = M; j->D = D; j->delta = delta; j->A = A; j->c = c; j->mean = mean;
+        j->inv_var = inv_var; j->det = det; j->X = X + f0 * D; j->len = len + u0; j->n_utt = u1 - u0;
+        j->stats = all + (size_t)t * ns;
+        for (int u = u0; u < u1; u++) f0 += (size_t)len[u];
+        u0 = u1;
+        if (pthread_create(&tid[t], NULL, orc_mt_run, j)) bad = 1, j->n_utt = -1;
+    }
+    memset(stats, 0, sizeof(double) * ns);
+    for (int t = 0; t < threads; t++) {
+        if (jobs[t].n_utt >= 0) pthread_join(tid[t], NULL);
+        if (jobs[t].n_utt < 0 || jobs[t].rc) bad = 1;
+        for (size_t k = 0; k < ns; k++) stats[k] += all[(size_t)t * ns + k];
+    }
+    free(jobs); free(tid); free(all);
+    return bad;
+}
+
 /* M-step from a stats vector, TF:332-346; model updated in place */
 void orc_mstep(int N, int M, int D, const double *stats, double *A, double *c, double *mean,
                double *inv_var, double *det)

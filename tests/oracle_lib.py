@@ -25,6 +25,8 @@ def lib():
         L.orc_stats_len.argtypes = [C.c_int] * 3
         L.orc_estep.restype = C.c_int
         L.orc_estep.argtypes = [C.c_int] * 4 + [_dp] * 6 + [_ip, C.c_int] + [_dp] * 7
+        L.orc_estep_mt.restype = C.c_int
+        L.orc_estep_mt.argtypes = [C.c_int] * 5 + [_dp] * 6 + [_ip, C.c_int, _dp]
         L.orc_mstep.restype = None
         L.orc_mstep.argtypes = [C.c_int] * 3 + [_dp] * 6
         L.orc_train.restype = C.c_int
@@ -83,6 +85,17 @@ def estep(hm, X, lens, delta=1, dumps=True):
                          _d(out.get("beta")), _d(out.get("scale")), _d(out.get("loglik")))
     assert rc == 0
     return stats, out
+
+
+def estep_mt(hm, X, lens, threads, delta=1):
+    """orc_estep over `threads` host threads (utterance blocks); returns the statistics vector."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    stats = np.zeros(stats_len(hm.N, hm.M, hm.D))
+    rc = lib().orc_estep_mt(threads, hm.N, hm.M, hm.D, delta, *_marr(hm), _d(X), lens.ctypes.data_as(_ip),
+                            len(lens), _d(stats))
+    assert rc == 0
+    return stats
 
 
 def mstep(hm, stats):
