@@ -361,14 +361,18 @@ def cpu_baseline(G, start, X, lens, budget_s):
                      f"benchmark corpus, oracle/ghmm_oracle.c (gcc -O2), {dt:.1f} s"}
     # SURVEY §8(d)'s optional second figure: the same E-step with the utterances dealt to every
     # host core this process may use (the reference itself is single-threaded)
+    # (threads = the CPUs this process may run on, at most 16: a one-GPU box's CPU share)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)
     if cores > 1:
-        nn = min(len(lens), max(cores, int(n * min(cores, 8) / 2)))
+        nn, reps, dt = len(lens), 0, 0.0
         t = time.perf_counter()
-        O.estep_mt(start, X[:nn * T], lens[:nn], cores)
-        dt = time.perf_counter() - t
-        out["all_cores"] = {"value": round(nn * T / dt, 1), "unit": "frames/s", "cores": cores,
-                            "sample": f"one E-step over the first {nn} utterances on {cores} threads, {dt:.1f} s"}
+        while dt < 3.0 and reps < 50:
+            O.estep_mt(start, X[:nn * T], lens[:nn], cores)
+            reps += 1
+            dt = time.perf_counter() - t
+        out["all_cores"] = {"value": round(reps * nn * T / dt, 1), "unit": "frames/s", "cores": cores,
+                            "sample": f"{reps} E-steps over {nn} utterances on {cores} threads, {dt:.1f} s"}
     return out
 
 

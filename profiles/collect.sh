@@ -26,4 +26,4 @@ stats m64 python3 bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 1 --
 echo "m64 done"
 stats refinit python3 profiles/train_trace.py
 echo "refinit done"
-tail -3 "$OUT"/*.log | tail -40
+for f in "$OUT"/*.log; do echo "== $f"; tail -n 3 "$f"; done

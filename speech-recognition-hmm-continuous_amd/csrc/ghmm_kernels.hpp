@@ -797,20 +797,35 @@ k_mixstats(int N, int M, int D, long long F, long long frames_per_block, int FS,
     }
     const long long fb0 = (long long)blockIdx.x * frames_per_block;
     const long long fb1 = (fb0 + frames_per_block < F) ? fb0 + frames_per_block : F;
+    // frames of the staged batch that carry weight for this block's Gaussians: gamma is exactly 0
+    // for most (frame, state) pairs, and a weight of exactly 0 adds exactly nothing — such frames
+    // are neither fetched nor visited
+    __shared__ unsigned long long nzmask;
     for (long long fs = fb0; fs < fb1; fs += FS) {
         const int nf = (int)((fb1 - fs) < FS ? (fb1 - fs) : FS);
         __syncthreads();
-        for (int k = tid; k < nf * D1; k += MS_THREADS) {
-            int r = k / D1, d = k - r * D1;
-            xs[k] = d < D ? X[(fs + r) * D + d] : 1.0;
-        }
+        if (tid == 0) nzmask = 0ull;
         for (int k = tid; k < nf * GW; k += MS_THREADS) {
             int r = k / GW, gl = k - r * GW;
             int g = real(g0 + gl);
             ws[k] = gamma[(fs + r) * N + g / M] * post[(fs + r) * G + g];
         }
         __syncthreads();
+        if (tid < nf) {
+            bool nz = false;
+            for (int gl = 0; gl < GW; gl++) nz |= ws[tid * GW + gl] != 0.0;
+            if (nz) atomicOr(&nzmask, 1ull << tid);
+        }
+        __syncthreads();
+        const unsigned long long nzm = nzmask; // FS <= 32 frames per batch
+        if (nzm == 0ull) continue;
+        for (int k = tid; k < nf * D1; k += MS_THREADS) {
+            int r = k / D1, d = k - r * D1;
+            if ((nzm >> r) & 1ull) xs[k] = d < D ? X[(fs + r) * D + d] : 1.0;
+        }
+        __syncthreads();
         for (int r = 0; r < nf; r++) {
+            if (!((nzm >> r) & 1ull)) continue;
 #pragma unroll
             for (int k = 0; k < MS_EPT; k++)
                 if (k < kmax) { // block-uniform: a short element range leaves the later slots empty
