@@ -1117,7 +1117,8 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
     // staged variant: every chunk of CT tiles must map to an even-aligned, even-length run of
     // real Gaussians (true when no mixture padding: Mp == M, M even) and N <= 16
     const int G = m->N * m->M;
-    const bool staged = m->Mp == m->M && (m->M % 2) == 0 && m->N <= 16 && (G % 2) == 0 &&
+    const bool staged = (((unsigned long long)c->X) & 15ull) == 0 && // (its frame pieces are 16-byte loads)
+                        m->Mp == m->M && (m->M % 2) == 0 && m->N <= 16 && (G % 2) == 0 &&
                         ((CT * 16) % 2) == 0 && ctx->kernels != 3;
     if (staged) {
         const int GWmax = CT * 16 < G ? CT * 16 : G;

@@ -1291,3 +1291,53 @@ def test_streams_command_lines(G, streams, tmp_path):
            if not l.startswith("Date and time") and "recognition time" not in l
            and not l.startswith("Model name")]
     assert got == streams["recog13_p2"]["report"]
+
+
+# ------------------------------------ the scheduled emission kernel, every instantiation
+
+@pytest.mark.parametrize("M,D", [(1, 39), (2, 38), (3, 37), (4, 36), (6, 39), (8, 36), (12, 38), (16, 37),
+                                 (24, 39), (32, 36), (48, 38), (64, 37)])
+def test_emission_kernel_instantiations(G, ctx, M, D):
+    """k_emission_sched<20, MP, OUT> for every mixture padding MP = 1..64 (M padded up: 3 -> 4, 6 -> 8,
+    12 -> 16, 24 -> 32, 48 -> 64) and every coefficient count it serves (36..39), in its three
+    output modes: b + posteriors (E-step), b (score) and log b (Viterbi), on a corpus whose last
+    frame tile is ragged, against the oracle."""
+    N = 5 if M >= 32 else 7
+    hm, X, lens = synth_case(G, N, M, D, [77, 130, 41], perturb=0.1)
+    ref_stats, ref = O.estep(hm, X, lens)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(N, M, D)
+    ctx.estep(model, corpus, stats)
+    F = corpus.frames
+    tag = f"M={M} D={D}: "
+    assert_frames(ctx.fetch(G.BUF_B, (F, N)), ref["b"], tag + "b")
+    assert_frames(ctx.fetch(G.BUF_POST, (F, N * M)), ref["post"].reshape(F, -1), tag + "post")
+    assert_close(stats.download(), ref_stats, what=tag + "stats")
+    assert_close(ctx.score(model, corpus), ref["loglik"], what=tag + "score")
+    path, score = ctx.viterbi(model, corpus)
+    o = 0
+    for T in lens:
+        p_ref, s_ref = O.viterbi(hm, X[o:o + T])
+        assert np.array_equal(path[o:o + T], p_ref), tag + "Viterbi path"
+        o += T
+    for o_ in (model, corpus, stats):
+        o_.close()
+
+
+def test_emission_frames_on_an_odd_8_byte_boundary(G, ctx):
+    """ghmm_corpus_wrap of a device pointer that is 8- but not 16-byte aligned: the emission
+    kernel's 8-byte tile loads and the statistics kernel's unstaged operands take over."""
+    import torch
+    hm, X, lens = synth_case(G, 10, 8, 39, [120, 77, 64])
+    buf = torch.zeros(X.size + 1, dtype=torch.float64, device="cuda:0")
+    buf[1:] = torch.from_numpy(X.ravel()).to("cuda:0")
+    torch.cuda.synchronize()
+    assert (buf.data_ptr() + 8) % 16 == 8
+    model = ctx.model(hm)
+    corpus = ctx.corpus_from_device(buf.data_ptr() + 8, lens, 39)
+    stats = ctx.stats(10, 8, 39)
+    ctx.estep(model, corpus, stats)
+    ref, _ = O.estep(hm, X, lens, dumps=False)
+    assert_close(stats.download(), ref, what="statistics from unaligned frames")
+    for o_ in (model, corpus, stats):
+        o_.close()
