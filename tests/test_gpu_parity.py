@@ -698,11 +698,11 @@ def _rank_worker(rank, world, port, q):
     stream = torch.cuda.Stream(device=0)
     torch.cuda.set_stream(stream)
     hm, X, lens = synth_case(G, 10, 8, 39, [90, 120, 65, 77, 101, 64, 88])
-    lo, hi = em.shard_range(len(lens), rank, world)
+    idx = em.shard_balanced(lens, rank, world)     # length-balanced shards, as bench.py / the C trainer
     off = np.concatenate([[0], np.cumsum(lens)])
     ctx = G.Context(0, stream=stream.cuda_stream)
     model = ctx.model(hm)
-    corpus = ctx.corpus(X[off[lo]:off[hi]], lens[lo:hi])
+    corpus = ctx.corpus(np.concatenate([X[off[u]:off[u + 1]] for u in idx]), lens[idx])
     be = em.HipBackend(G, ctx, model, corpus, torch=torch)
     drv = em.EMDriver(be, dist)
     trace = []
