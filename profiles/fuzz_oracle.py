@@ -1,7 +1,7 @@
 """Fuzz: the product's E-step + M-step (default tier) against the oracle (oracle/ghmm_oracle.c, the
 CPU restatement pinned to the reference) on seeded random shapes — the body is
 tests/test_gpu_parity.py:fuzz_estep_case (20 seeds of it run in the -m gpu suite).
-usage: fuzz_oracle.py [n_seeds]"""
+usage: fuzz_oracle.py [n_seeds] [wide]   (wide: shapes up to 64 states x 64 mixtures x 64 coefficients)"""
 import sys
 sys.path.insert(0, "tests")
 from _load import load_pkg
@@ -10,11 +10,12 @@ import test_gpu_parity as T
 G = load_pkg().ghmm
 ctx = G.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+wide = "wide" in sys.argv[2:]
 bad = 0
 for seed in range(n):
     try:
-        T.fuzz_estep_case(G, ctx, seed)
+        T.fuzz_estep_case(G, ctx, seed, wide=wide)
     except AssertionError as e:
         bad += 1
         print(str(e)[:240])
-print(f"{n} shapes against the oracle, {bad} disagreements")
+print(f"{n} {'wide ' if wide else ''}shapes against the oracle, {bad} disagreements")

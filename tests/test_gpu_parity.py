@@ -810,12 +810,25 @@ def test_collapsed_components_sharing_a_tile(G, ctx):
 
 # ------------------------------------------------ fuzz against the oracle (seeded shapes)
 
-def fuzz_estep_case(G, ctx, seed):
+def fuzz_shape(rng, wide):
+    """(states, mixtures, coefficients) of one fuzz case.  wide: up to the library's 64 states,
+    64 mixtures and 64 coefficients, and half of the cases on the 36..40-coefficient shapes the
+    scheduled emission kernel serves."""
+    if not wide:
+        return int(rng.integers(1, 21)), int(rng.integers(1, 12)), int(rng.integers(1, 45))
+    N = int(rng.choice([1, 2, 3, 5, 10, 16, 17, 31, 32, 48, 64]))
+    M = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 24, 32, 33, 64]))
+    D = int(rng.integers(36, 41)) if rng.integers(0, 2) else int(rng.choice([1, 8, 13, 26, 45, 52, 64]))
+    return N, M, D
+
+
+def fuzz_estep_case(G, ctx, seed, wide=False):
     """E-step + M-step of the default tier against the oracle on one seeded random shape
-    (1-20 states, 1-11 mixtures, 1-44 coefficients, dense or band-diagonal A, band 0..3).
-    profiles/fuzz_oracle.py runs the same body over hundreds of seeds."""
-    rng = np.random.default_rng(9000 + seed)
-    N, M, D = int(rng.integers(1, 21)), int(rng.integers(1, 12)), int(rng.integers(1, 45))
+    (1-20 states, 1-11 mixtures, 1-44 coefficients, dense or band-diagonal A, band 0..3; wide:
+    fuzz_shape's larger shapes).  profiles/fuzz_oracle.py runs the same body over hundreds of
+    seeds."""
+    rng = np.random.default_rng((19000 if wide else 9000) + seed)
+    N, M, D = fuzz_shape(rng, wide)
     # every utterance can reach the last state
     lens = [int(x) for x in rng.integers(N, N + 120, size=int(rng.integers(1, 7)))]
     dense, delta = bool(rng.integers(0, 2)), int(rng.integers(0, 4))
@@ -844,12 +857,12 @@ def fuzz_estep_case(G, ctx, seed):
             o.close()
 
 
-def fuzz_viterbi_case(G, ctx, seed):
+def fuzz_viterbi_case(G, ctx, seed, wide=False):
     """Viterbi state sequences (bit-identical) and forward scores against the oracle on one
     seeded random shape; profiles/fuzz_viterbi.py runs it over more seeds.  Returns the number
     of utterances checked."""
-    rng = np.random.default_rng(7000 + seed)
-    N, M, D = int(rng.integers(1, 21)), int(rng.integers(1, 12)), int(rng.integers(1, 45))
+    rng = np.random.default_rng((17000 if wide else 7000) + seed)
+    N, M, D = fuzz_shape(rng, wide)
     lens = [int(x) for x in rng.integers(1, 150, size=int(rng.integers(1, 6)))]
     dense = bool(rng.integers(0, 2))
     hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense, seed=seed,
@@ -883,6 +896,13 @@ def test_fuzz_estep_against_oracle(G, ctx, seed):
 @pytest.mark.parametrize("seed", list(range(20)))
 def test_fuzz_viterbi_against_oracle(G, ctx, seed):
     fuzz_viterbi_case(G, ctx, seed)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_wide_shapes_against_oracle(G, ctx, seed):
+    """The same two bodies on shapes up to 64 states x 64 mixtures x 64 coefficients."""
+    fuzz_estep_case(G, ctx, seed, wide=True)
+    fuzz_viterbi_case(G, ctx, seed, wide=True)
 
 
 # ------------------------------------------------------------------- boundary
