@@ -82,7 +82,11 @@ enum {
     /* 1: bracket every kernel with HIP events on the context's stream */
     GHMM_OPT_TIMING = 4,
     /* number of frame-block partial sums kept by the statistics kernel (0 auto) */
-    GHMM_OPT_PARTIALS = 5
+    GHMM_OPT_PARTIALS = 5,
+    /* compute units the one-block-per-CU kernels size their grids for (0 = all of the
+     * device's, the default): for a caller whose stream is restricted to part of the device
+     * (hipExtStreamCreateWithCUMask) */
+    GHMM_OPT_CUS = 6
 };
 int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value);
 int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value);

@@ -52,7 +52,7 @@ struct ghmm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int cus = 256;
+    int cus = 256, dev_cus = 256; // grid sizing (GHMM_OPT_CUS) / the device's count
     int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0;
     // workspace (grown on demand, never shrunk)
     size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
@@ -308,6 +308,7 @@ extern "C" int ghmm_ctx_create(int device, void *hip_stream, ghmm_ctx **out)
     if (!ctx) return GHMM_ERR_ALLOC;
     ctx->device = device;
     ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->dev_cus = ctx->cus;
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {
@@ -380,6 +381,10 @@ extern "C" int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value)
         ARG_CHECK(value >= 0 && value <= 65535, "partials out of range");
         ctx->partials = value;
         break;
+    case GHMM_OPT_CUS:
+        ARG_CHECK(value >= 0 && value <= ctx->dev_cus, "compute units out of range");
+        ctx->cus = value ? (int)value : ctx->dev_cus;
+        break;
     default:
         ghmm_set_error("unknown option %d", option);
         return GHMM_ERR_ARG;
@@ -396,6 +401,7 @@ extern "C" int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value)
     case GHMM_OPT_KERNELS: *value = ctx->kernels; break;
     case GHMM_OPT_TIMING: *value = ctx->timing; break;
     case GHMM_OPT_PARTIALS: *value = ctx->partials; break;
+    case GHMM_OPT_CUS: *value = ctx->cus; break;
     default:
         ghmm_set_error("unknown option %d", option);
         return GHMM_ERR_ARG;

@@ -509,6 +509,25 @@ def test_delta_option_widens_the_transition_band(G, ctx):
         o.close()
 
 
+def test_grids_sized_for_part_of_the_device(G, ctx):
+    """GHMM_OPT_CUS (a caller whose stream is CU-masked): the one-block-per-CU kernels sized for
+    a few compute units give the oracle's sums like the full-device grids do."""
+    hm, X, lens = synth_case(G, 10, 8, 39, [300, 211, 128, 77, 64, 500, 333, 90])
+    ref, _ = O.estep(hm, X, lens, dumps=False)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    try:
+        for cus in (3, 64, 0):
+            ctx.set_option(G.OPT_CUS, cus)
+            ctx.estep(model, corpus, stats)
+            assert_close(stats.download(), ref, what=f"cus={cus}")
+        assert ctx.get_option(G.OPT_CUS) >= 64   # 0 = the device's own count
+    finally:
+        ctx.set_option(G.OPT_CUS, 0)
+    for o in (model, corpus, stats):
+        o.close()
+
+
 def test_viterbi_paths_identical_to_oracle(G, ctx):
     """State sequences bit-identical, scores within 1e-10 (index work: exact)."""
     for N, M, D, lens, dense in [(10, 8, 39, [300, 150, 64, 10, 1], False),
