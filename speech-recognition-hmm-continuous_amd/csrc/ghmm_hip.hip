@@ -79,6 +79,8 @@ struct ghmm_ctx {
     double *part_mu = nullptr, *part_var = nullptr, *part_m = nullptr;
     // several feature streams: the stream being evaluated (b^p) and every stream's posteriors
     double *b_stream = nullptr;
+    double *b_alloc = nullptr; // b sits B_PAD_FRAMES rows inside this allocation (grow_b)
+    size_t b_pad = 0;
     size_t cap_b_stream = 0;
     std::vector<double *> post_s;
     std::vector<size_t> cap_post_s;
@@ -329,7 +331,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    void *bufs[] = {ctx->b,       ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
+    void *bufs[] = {ctx->b_alloc, ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
                     ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb,
@@ -820,11 +822,30 @@ static int check_pair(const ghmm_model *m, const ghmm_corpus *c)
     return GHMM_OK;
 }
 
+// b[F][N] with B_PAD_FRAMES rows of padding on either side: the scans' operand cursors run past
+// the ends of an utterance without a clamp (ghmm_kernels.hpp forward_run); nothing read there is used
+static int grow_b(ghmm_ctx *ctx, size_t F, size_t N)
+{
+    const size_t pad = (size_t)B_PAD_FRAMES * N, need = F * N;
+    if (ctx->b_alloc && ctx->b_pad >= pad && ctx->b_pad + need + pad <= ctx->cap_b) return GHMM_OK;
+    if (ctx->b_alloc) HIP_TRY(hipFree(ctx->b_alloc));
+    ctx->b_alloc = ctx->b = nullptr;
+    ctx->cap_b = ctx->b_pad = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->b_alloc, (need + 2 * pad + 1) * sizeof(double)));
+    // (defined contents for the rows no frame owns)
+    HIP_TRY(hipMemsetAsync(ctx->b_alloc, 0, pad * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->b_alloc + pad + need, 0, (pad + 1) * sizeof(double), ctx->stream));
+    ctx->cap_b = need + 2 * pad + 1;
+    ctx->b_pad = pad;
+    ctx->b = ctx->b_alloc + pad;
+    return GHMM_OK;
+}
+
 static int ws_frames(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c, bool want_post)
 {
     int rc;
     size_t F = (size_t)c->F, N = (size_t)m->N, G = (size_t)m->N * m->M;
-    if ((rc = dev_grow(&ctx->b, &ctx->cap_b, F * N))) return rc;
+    if ((rc = grow_b(ctx, F, N))) return rc;
     if (want_post && (rc = dev_grow(&ctx->post, &ctx->cap_post, F * G))) return rc;
     if ((rc = dev_grow(&ctx->scale, &ctx->cap_scale, F))) return rc;
     if ((rc = dev_grow(&ctx->sinv, &ctx->cap_sinv, F))) return rc;
@@ -1778,7 +1799,7 @@ extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_
     if ((rc = fb_lanes(m, &L))) return rc;
     ARG_CHECK(m->N <= 255, "too many states for byte back-pointers");
     if ((rc = ws_frames(ctx, m, c, false))) return rc;
-    if ((rc = dev_grow(&ctx->psi, &ctx->cap_psi, (size_t)c->F * m->N))) return rc;
+    if ((rc = dev_grow(&ctx->psi, &ctx->cap_psi, (size_t)c->F * L + 16))) return rc; // rows of L bytes
     if ((rc = dev_grow(&ctx->path, &ctx->cap_path, (size_t)c->F))) return rc;
     if ((rc = run_emission(ctx, m, c, 2, false))) return rc;
     if (c->U) {
@@ -1788,10 +1809,10 @@ extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_
             kscope ks(ctx, GHMM_K_VITERBI);
             if (L == 16)
                 hipLaunchKernelGGL(k_viterbi<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
-                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, c->order);
+                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, ctx->sink, c->order);
             else
                 hipLaunchKernelGGL(k_viterbi<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
-                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, c->order);
+                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, ctx->sink, c->order);
         }
         if ((rc = launch_ok("k_viterbi"))) return rc;
         HIP_TRY(hipMemcpyAsync(score_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,

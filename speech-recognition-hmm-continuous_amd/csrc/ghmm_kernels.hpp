@@ -282,6 +282,9 @@ __device__ inline double *wave_sink(double *sink)
 
 constexpr int PF = 8;   // frames of b / alpha prefetched ahead of the serial recursion
 constexpr int PFF = 16; // the same for the forward pass (one operand stream, more room)
+// frames of padding the host keeps in front of and behind the emission densities b[F][N]: the
+// scans' operand cursors run up to 2 PFF frames past either end of an utterance
+constexpr int B_PAD_FRAMES = 2 * PFF;
 
 // ------------------------------------------------------------------ forward
 // calc_alpha (TF:1380-1443 = RF:739-799) with pi = one-hot at state 0 (TF:232-234)
@@ -366,17 +369,23 @@ __device__ __forceinline__ double forward_run(int N, int T, int i, bool act, con
     const int da = (act && au) ? N : 0;
     double *pcs = (i == 0) ? su : ((SINV && i == 1) ? si : sink);
     const int dc = (i == 0 || (SINV && i == 1)) ? 1 : 0;
-    const double *pb = act ? bu + i : sink + WAVE; // frame 0 of b (idle lanes: zeros, stride 0)
-    const int db = act ? bstride : 0;
-    // b of frame f, clamped into the utterance: loads are never predicated (a load under
-    // a branch makes hipcc wait vmcnt(0) at every step)
-    // (idle lanes read the zero half of the sink buffer, which nothing writes: no `act ?`
-    // here, it would predicate the load)
-    auto bget = [&](int f) { return pb[(size_t)(f < T ? f : T - 1) * db]; };
+    // b of frame 0, 1, 2, ... through a cursor that is never clamped and never predicated (a
+    // load under a branch makes hipcc wait vmcnt(0) at every step; an index clamp costs six
+    // vector instructions per load): the prefetch runs up to 2 PFF frames past the utterance,
+    // into the next utterance's rows or the padding the host keeps behind b (B_PAD_FRAMES);
+    // what it reads there is never used.  Idle lanes read the zero half of the sink buffer,
+    // which nothing writes, with stride 0 (no `act ?` on the load, it would predicate it).
+    const double *pl = act ? bu + i : sink + WAVE;
+    const ptrdiff_t db = act ? bstride : 0;
+    auto bnext = [&]() {
+        const double v = *pl;
+        pl += db;
+        return v;
+    };
 
     // t = 0
     {
-        const double a0 = ((i == 0) ? 1.0 : 0.0) * bget(0);
+        const double a0 = ((i == 0) ? 1.0 : 0.0) * bnext();
         const double s = group_sum<L>(a0);
         const double c = recip_select(s);
         st.a = a0 * c;
@@ -387,11 +396,11 @@ __device__ __forceinline__ double forward_run(int N, int T, int i, bool act, con
     double bq[PFF];
     int t = 1;
 #pragma unroll
-    for (int k = 0; k < PFF; k++) bq[k] = bget(t + k);
+    for (int k = 0; k < PFF; k++) bq[k] = bnext();
     for (; t + PFF <= T; t += PFF) {
         double bn[PFF];
 #pragma unroll
-        for (int k = 0; k < PFF; k++) bn[k] = bget(t + PFF + k);
+        for (int k = 0; k < PFF; k++) bn[k] = bnext();
         if (BANDED) {
 #pragma unroll
             for (int k = 0; k < PFF; k++) {
@@ -1296,11 +1305,97 @@ k_init_classify(int N, int M, int D, int n_cells, int U, long long F,
 //   delta_0(j) = (j == 0 ? 0 : -inf) + logb_j(0)
 //   delta_t(j) = max_i (delta_{t-1}(i) + log a_ij) + logb_j(t), ties -> lowest i
 //   score = delta_{T-1}(N-1); path by back-pointers from state N-1.
+// One group of L lanes per utterance, lane = state.  Like the forward pass the time loop is
+// branch-free (operand cursor without clamp, idle lanes store into the sink) and log A's band
+// structure is chosen once per wave: for a left-to-right model only the candidates i = j-1 and
+// i = j exist (every other log a_ij is -inf and can never win a strict `>`), taken with one DPP
+// row shift instead of N lane reads.  Back-pointers are one byte, rows of L bytes per frame.
+template <int L, bool BANDED>
+__device__ __forceinline__ double viterbi_run(int N, int T, int j, bool act, const double *__restrict__ logA,
+                                     const double *__restrict__ lb, unsigned char *__restrict__ ps,
+                                     double *__restrict__ sink)
+{
+    double lacol[BANDED ? 1 : L];
+    if (!BANDED) {
+#pragma unroll
+        for (int i = 0; i < L; i++) lacol[BANDED ? 0 : i] = (act && i < N) ? logA[i * N + j] : -INFINITY;
+    }
+    const double la_self = act ? logA[j * N + j] : -INFINITY;
+    const double la_prev = (act && j > 0) ? logA[(j - 1) * N + j] : -INFINITY;
+    // idle lanes: zeros from the sink's read-only half (stride 0), back-pointers into its other half
+    const double *pl = act ? lb + j : sink + WAVE;
+    const ptrdiff_t db = act ? N : 0;
+    unsigned char *pp = act ? ps + j : (unsigned char *)sink;
+    const ptrdiff_t dp = act ? L : 0;
+    auto bnext = [&]() {
+        const double v = *pl;
+        pl += db;
+        return v;
+    };
+    double d = ((j == 0) ? 0.0 : -INFINITY) + bnext();
+    *pp = 0;
+    pp += dp;
+    auto step = [&](double q) {
+        double best = -INFINITY;
+        int arg = 0;
+        if (BANDED) {
+            const double c1 = group_up1<L>(d) + la_prev; // predecessor j-1 (the lower index first)
+            const double c0 = d + la_self;
+            if (c1 > best) {
+                best = c1;
+                arg = j - 1;
+            }
+            if (c0 > best) {
+                best = c0;
+                arg = j;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < L; i++)
+                if (i < N) {
+                    const double v = __shfl(d, i, L) + lacol[BANDED ? 0 : i];
+                    if (v > best) {
+                        best = v;
+                        arg = i;
+                    }
+                }
+        }
+        d = best + q;
+        *pp = (unsigned char)arg;
+        pp += dp;
+    };
+    double q[PF];
+    int t = 1;
+#pragma unroll
+    for (int k = 0; k < PF; k++) q[k] = bnext();
+    for (; t + PF <= T; t += PF) {
+        double qn[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) qn[k] = bnext();
+#pragma unroll
+        for (int k = 0; k < PF; k++) step(q[k]);
+#pragma unroll
+        for (int k = 0; k < PF; k++) q[k] = qn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; k++)
+        if (t + k < T) step(q[k]);
+    return d;
+}
+
+// byte s (0..15) of a 16-byte back-pointer row
+__device__ __forceinline__ int psi_byte(const uint4 r, int s)
+{
+    const unsigned lo = (s & 4) ? r.y : r.x, hi = (s & 4) ? r.w : r.z;
+    const unsigned w = (s & 8) ? hi : lo;
+    return (int)((w >> ((s & 3) * 8)) & 0xffu);
+}
+
 template <int L>
 __global__ void __launch_bounds__(WAVE)
 k_viterbi(int N, int U, const double *__restrict__ logA, const double *__restrict__ logb,
           const long long *__restrict__ off, unsigned char *__restrict__ psi,
-          unsigned char *__restrict__ path, double *__restrict__ score,
+          unsigned char *__restrict__ path, double *__restrict__ score, double *__restrict__ sink,
           const int *__restrict__ order)
 {
     const int slot = blockIdx.x * (WAVE / L) + threadIdx.x / L;
@@ -1314,50 +1409,45 @@ k_viterbi(int N, int U, const double *__restrict__ logA, const double *__restric
         return;
     }
     const bool act = j < N;
-    double lacol[L];
+    bool offband = false;
+    for (int i = 0; i < N; i++)
+        offband |= act && (logA[i * N + j] != -INFINITY && i != j && i != j - 1);
+    const bool banded = !__any(offband);
+    unsigned char *ps = psi + (size_t)f0 * L; // rows of L bytes
+    double *snk = wave_sink(sink);
+    double d;
+    if (banded) d = viterbi_run<L, true>(N, T, j, act, logA, logb + f0 * N, ps, snk);
+    else d = viterbi_run<L, false>(N, T, j, act, logA, logb + f0 * N, ps, snk);
+    const double sc = __shfl(d, N - 1, L);
+    __threadfence_block();
+    if (j != 0) return;
+    score[u] = sc;
+    int s = N - 1;
+    unsigned char *pu = path + f0;
+    if (L == 16) {
+        // whole 16-byte rows, read ahead of the chain (their addresses do not depend on it):
+        // the chain itself is a byte select in registers
+        constexpr int PB = 8;
+        const uint4 *rows = (const uint4 *)ps;
+        int t = T - 1;
+        for (; t - PB + 1 >= 0; t -= PB) {
+            uint4 r[PB];
 #pragma unroll
-    for (int i = 0; i < L; i++) lacol[i] = (act && i < N) ? logA[i * N + j] : -INFINITY;
-    const double *lb = logb + f0 * N;
-    unsigned char *ps = psi + f0 * N;
-    double d = ((j == 0) ? 0.0 : -INFINITY) + (act ? lb[j] : -INFINITY);
-    if (act) ps[j] = 0;
-    double q[PF], qn[PF];
+            for (int k = 0; k < PB; k++) r[k] = rows[t - k];
 #pragma unroll
-    for (int k = 0; k < PF; k++) q[k] = (act && 1 + k < T) ? lb[(size_t)(1 + k) * N + j] : 0.0;
-    for (int tb = 1; tb < T; tb += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; k++)
-            qn[k] = (act && tb + PF + k < T) ? lb[(size_t)(tb + PF + k) * N + j] : 0.0;
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int t = tb + k;
-            if (t < T) {
-                double best = -INFINITY;
-                int arg = 0;
-#pragma unroll
-                for (int i = 0; i < L; i++)
-                    if (i < N) {
-                        double v = __shfl(d, i, L) + lacol[i];
-                        if (v > best) {
-                            best = v;
-                            arg = i;
-                        }
-                    }
-                d = best + q[k];
-                if (act) ps[(size_t)t * N + j] = (unsigned char)arg;
+            for (int k = 0; k < PB; k++) {
+                pu[t - k] = (unsigned char)s;
+                s = psi_byte(r[k], s);
             }
         }
-#pragma unroll
-        for (int k = 0; k < PF; k++) q[k] = qn[k];
-    }
-    double sc = __shfl(d, N - 1, L);
-    __threadfence_block();
-    if (j == 0) {
-        score[u] = sc;
-        int s = N - 1;
+        for (; t >= 0; t--) {
+            pu[t] = (unsigned char)s;
+            s = psi_byte(rows[t], s);
+        }
+    } else {
         for (int t = T - 1; t >= 0; t--) {
-            path[f0 + t] = (unsigned char)s;
-            s = ps[(size_t)t * N + s];
+            pu[t] = (unsigned char)s;
+            s = ps[(size_t)t * L + s];
         }
     }
 }

@@ -68,20 +68,24 @@ __device__ __forceinline__ void backward_own_run(int N, int T, int i, bool act, 
         *ps = r;
         pw -= dn; ps -= ds;
     };
-    auto bget = [&](int t) { // b of frame t + 1, clamped into the utterance
-        int f = t + 1;
-        f = f < 0 ? 0 : (f < T ? f : T - 1);
-        return pb0[(size_t)f * dn];
+    // b of frame T-1, T-2, ... (frame t+1 for t = T-2 .. 0) through a descending cursor, PFF
+    // steps ahead, neither clamped nor predicated: it runs up to 2 PFF frames in front of the
+    // utterance (the previous utterance's rows or the padding in front of b, B_PAD_FRAMES)
+    const double *pl = pb0 + (ptrdiff_t)(T - 1) * dn;
+    const ptrdiff_t dnl = dn;
+    auto bnext = [&]() {
+        const double v = *pl;
+        pl -= dnl;
+        return v;
     };
-    // b of frame t+1 for t = T-2 .. 0, prefetched PFF steps ahead with clamped addresses
     double bq[PFF];
     int t = T - 2;
 #pragma unroll
-    for (int k = 0; k < PFF; k++) bq[k] = bget(t - k);
+    for (int k = 0; k < PFF; k++) bq[k] = bnext();
     for (; t - PFF + 1 >= 0; t -= PFF) {
         double bn[PFF];
 #pragma unroll
-        for (int k = 0; k < PFF; k++) bn[k] = bget(t - PFF - k);
+        for (int k = 0; k < PFF; k++) bn[k] = bnext();
 #pragma unroll
         for (int k = 0; k < PFF; k++) step(bq[k]);
 #pragma unroll
