@@ -24,7 +24,10 @@
 
 namespace ghmm {
 
-constexpr int CB_CH = 8; // chunks of an utterance handled by different groups of k_combine
+#ifndef GHMM_CB_CH
+#define GHMM_CB_CH 8 // (measurement builds override it: profiles/tools/lab.sh)
+#endif
+constexpr int CB_CH = GHMM_CB_CH; // chunks of an utterance handled by different groups of k_combine
 constexpr int CB_PF = 4; // frames of operands read ahead in k_combine (x 2 register sets x 4 operands)
 
 template <int L, bool BANDED>
