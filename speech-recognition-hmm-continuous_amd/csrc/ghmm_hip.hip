@@ -513,7 +513,7 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
         // the scheduled kernel (12 slabs of DP + 2 doubles): as many whole states per chunk as
         // fit beside them, up to 8 tiles — every chunk stages the frames again
         {
-            int tcs = 8 / m->tps * m->tps;
+            int tcs = GHMM_EMS_TC / m->tps * m->tps;
             while (tcs > m->tps && ems_lds_bytes(tcs, m->DP, ems_waves(Mp)) > 159 * 1024) tcs -= m->tps;
             if (tcs > m->NT) tcs = m->NT;
             m->TCs = tcs > TC ? tcs : TC;

@@ -532,7 +532,13 @@ constexpr int EMS_WAVES = 16;
 // waves per block: 12 (3 per SIMD, 168 registers each) hold the x operands of a frame tile
 // (x', x'^2: 40 registers), the next frame tile on its way from HBM (20) and, where a state
 // spans 2 or 4 tiles, the densities of those tiles until the state's sum is known
-__host__ __device__ constexpr int ems_waves(int MP) { return MP >= 32 ? 12 : GHMM_EMS_W; }
+#ifndef GHMM_EMS_W32
+#define GHMM_EMS_W32 12 // the same for states of 32 / 64 mixtures
+#endif
+#ifndef GHMM_EMS_TC
+#define GHMM_EMS_TC 8 // most Gaussian tiles per chunk (each chunk stages the frames again)
+#endif
+__host__ __device__ constexpr int ems_waves(int MP) { return MP >= 32 ? GHMM_EMS_W32 : GHMM_EMS_W; }
 
 // 2^(j/32), j = 0..31, correctly rounded
 __device__ const double EXP2_32[32] = {
