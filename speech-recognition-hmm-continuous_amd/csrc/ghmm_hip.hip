@@ -80,6 +80,8 @@ struct ghmm_ctx {
     // several feature streams: the stream being evaluated (b^p) and every stream's posteriors
     double *b_stream = nullptr;
     double *b_alloc = nullptr; // b sits B_PAD_FRAMES rows inside this allocation (grow_b)
+    unsigned *smask = nullptr; // states occupied in each 16-frame stage (k_stage_masks)
+    size_t cap_smask = 0;
     size_t b_pad = 0;
     size_t cap_b_stream = 0;
     std::vector<double *> post_s;
@@ -335,7 +337,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
                     ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb,
-                    ctx->lpart,   ctx->logk,      ctx->b_stream};
+                    ctx->lpart,   ctx->logk,      ctx->b_stream,  ctx->smask};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (double *p : ctx->post_s)
@@ -1162,14 +1164,37 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
         int rc;
         if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true>))) return rc;
         if (lds <= 150 * 1024) {
+            // Several chunks (e.g. 64 mixtures: 8 chunks of little more than one state): each
+            // chunk's launch walks only the stages in which one of its states is occupied, from
+            // a per-stage state mask taken once from gamma.
+            bool masked = false;
+            if constexpr (NE == 5) {
+                if (chunks > 1 && c->F >= 16) {
+                    const size_t nst = (size_t)((c->F + 15) / 16);
+                    if ((rc = dev_grow(&ctx->smask, &ctx->cap_smask, nst))) return rc;
+                    if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true, true>))) return rc;
+                    hipLaunchKernelGGL(k_stage_masks, dim3((unsigned)((c->F + WAVE - 1) / WAVE)), dim3(WAVE), 0,
+                                       ctx->stream, m->N, c->F, ctx->gamma, ctx->smask);
+                    masked = true;
+                }
+            }
             // one launch per chunk so that gmin / GW are plain arguments (chunks == 1 at 10x8)
             for (int ch = 0; ch < chunks; ch++) {
                 const int gmin = ch * CT * 16;
                 int GW = G - gmin < CT * 16 ? G - gmin : CT * 16;
+                if constexpr (NE == 5) {
+                    if (masked) {
+                        hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true, true>), dim3((unsigned)P, 1u),
+                                           dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
+                                           m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
+                                           m->gmap + 0, m->oglob, ctx->part_m, ctx->smask);
+                        continue;
+                    }
+                }
                 hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true>), dim3((unsigned)P, 1u),
                                    dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
                                    m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
-                                   m->gmap + 0, m->oglob, ctx->part_m);
+                                   m->gmap + 0, m->oglob, ctx->part_m, (const unsigned *)nullptr);
             }
             return GHMM_OK;
         }
@@ -1178,7 +1203,8 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
     if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, false>))) return rc;
     hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, false>), dim3((unsigned)P, (unsigned)chunks),
                        dim3(MSM_WAVES * WAVE), fold, ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT,
-                       c->F, 0, 0, c->X, ctx->gamma, ctx->post, m->gmap, m->oglob, ctx->part_m);
+                       c->F, 0, 0, c->X, ctx->gamma, ctx->post, m->gmap, m->oglob, ctx->part_m,
+                       (const unsigned *)nullptr);
     return GHMM_OK;
 }
 

@@ -1062,18 +1062,44 @@ __device__ inline void divmod_small(int e, int d, float rd, int &q, int &r)
 }
 
 constexpr int MSM_WAVES = 4;
+
+// smask[stage] bit i = gamma_t(i) != 0 for some frame t of the 16-frame stage (N <= 32).  One
+// wave per 4 stages, lane = frame.
+__global__ void __launch_bounds__(WAVE)
+k_stage_masks(int N, long long F, const double *__restrict__ gamma, unsigned *__restrict__ smask)
+{
+    const int l = threadIdx.x;
+    const long long f = ((long long)blockIdx.x * WAVE) + l;
+    const bool ok = f < F;
+    const double *g = gamma + (ok ? f : F - 1) * N;
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < N; i++) {
+        const unsigned long long nz = __ballot(ok && g[i] != 0.0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) m[q] |= ((nz >> (16 * q)) & 0xffffull) != 0ull ? (1u << i) : 0u;
+    }
+    const long long st = (long long)blockIdx.x * 4 + l;
+    if (l < 4 && st * 16 < F) smask[st] = l == 0 ? m[0] : (l == 1 ? m[1] : (l == 2 ? m[2] : m[3]));
+}
 constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
 // STAGED = true: frames go HBM -> registers -> LDS in 16-frame stages with fully
 // coalesced 16-byte-per-lane loads (one stage ahead), MFMA operands come from LDS.
 // Needs G, gmin, GW even (16-byte alignment of the posterior rows) and N <= 16.
 // STAGED = false: operands straight from HBM, 8 bytes per lane (any shape).
-template <int CT, int NE, bool STAGED>
+// MASKED (staged only): the states that carry weight in every 16-frame stage come from
+// smask[stage] (k_stage_masks) instead of from gamma travelling a stage ahead, and the wave
+// walks ONLY the stages in which a state of this chunk's tiles is occupied.  For models whose
+// Gaussians take several chunks (64 mixtures: 8 chunks of little more than one state each) most
+// stages of a chunk are empty, and an empty stage then costs a bit test instead of a trip to
+// memory.
+template <int CT, int NE, bool STAGED, bool MASKED = false>
 __global__ void __launch_bounds__(MSM_WAVES *WAVE, 1)
 k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gmin, int GW,
                 const double *__restrict__ X, const double *__restrict__ gamma,
                 const double *__restrict__ post, const int *__restrict__ gmap,
-                const double *__restrict__ oglob, double *__restrict__ part)
+                const double *__restrict__ oglob, double *__restrict__ part,
+                const unsigned *__restrict__ smask = nullptr)
 {
     extern __shared__ double lds[]; // fold: [CT*NE*4][64]; STAGED: per-wave frame stages
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
@@ -1224,21 +1250,61 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
 #pragma unroll
             for (int u = 0; u < NGL; u++) q[u] = gsrc[pcg[u]];
         };
-        // frames and the posteriors of the states in `smask` (the others: the stage's first piece)
+        // states of this chunk's tiles: a stage in which none of them carries weight is not
+        // staged at all (with 64 mixtures a chunk of 5 tiles is little more than one state, and a
+        // state is occupied in a small part of the frames)
+        unsigned cmask = 0;
+#pragma unroll
+        for (int c = 0; c < CT; c++) cmask |= tm[c];
+        // frames and the posteriors of the states in `smask` (the others: the stage's first piece;
+        // no state of the chunk in the mask: the frames' first piece as well)
         auto fetch = [&](long long stg, unsigned smask) {
             const long long f = stg * 16;
             const v2d *xsrc = (const v2d *)(X + uniform64(f * D));
             const double *psrc = post + uniform64(f * G + gmin);
+            const unsigned xm = (smask & cmask) != 0u ? ~0u : 0u; // wave-uniform
 #pragma unroll
-            for (int u = 0; u < NXL; u++) rx[u] = xsrc[pcx[u]];
+            for (int u = 0; u < NXL; u++) rx[u] = xsrc[pcx[u] & xm];
 #pragma unroll
             for (int u = 0; u < NPL; u++) {
                 const unsigned o = ((smask >> pst[u]) & 1u) ? offp[u] - (unsigned)gmin : 0u;
                 rp[u] = *(const v2d *)(psrc + o);
             }
         };
+        // MASKED: next stage >= from (< s1) with a state of this chunk in its mask, and that mask;
+        // the masks of 64 consecutive stages sit one per lane, their "occupied" bits in a scalar pair
+        long long blk_base = -64;
+        unsigned long long blk_bits = 0;
+        unsigned blk_val = 0;
+        auto next_active = [&](long long from, unsigned &mval) -> long long {
+            while (from < s1) {
+                if (from >= blk_base + 64) {
+                    blk_base = from;
+                    const long long sl = from + l < s1 ? from + l : s1 - 1;
+                    blk_val = smask[sl];
+                    blk_bits = __ballot((blk_val & cmask) != 0u && from + l < s1);
+                }
+                const int rel = (int)(from - blk_base);
+                const unsigned long long rem = blk_bits >> rel;
+                if (rem) {
+                    const int at = rel + __builtin_ctzll(rem);
+                    mval = (unsigned)__builtin_amdgcn_readlane((int)blk_val, at);
+                    return blk_base + at;
+                }
+                from = blk_base + 64;
+            }
+            mval = 0;
+            return s1;
+        };
         unsigned smask_cur = 0;
-        if (s0 < s1) {
+        long long cur = s0; // MASKED: the stage being staged
+        if (MASKED) {
+            cur = next_active(s0, smask_cur);
+            if (cur < s1) {
+                fetch_gamma(cur, rg);
+                fetch(cur, smask_cur);
+            }
+        } else if (s0 < s1) {
             fetch_gamma(s0, rg);
             fetch_gamma(s0 + 1 < s1 ? s0 + 1 : s0, rgn);
             smask_cur = state_mask(rg);
@@ -1249,26 +1315,37 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
             for (int col = l; col < XS; col += WAVE) fx[r * XS + col] = col == D ? 1.0 : 0.0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (long long stg = s0; stg < s1; stg++) {
+        for (long long stg = MASKED ? cur : s0; stg < s1; stg = MASKED ? cur : stg + 1) {
+            if (MASKED || (smask_cur & cmask) != 0u) {
 #pragma unroll
-            for (int u = 0; u < NXL; u++) {
-                const double x0 = rx[u][0] - ol[xa[u] & 255u], x1 = rx[u][1] - ol[xb[u] & 255u];
-                fx[xa[u] >> 8] = x0;
-                fx[(xa[u] >> 8) + DP] = x0 * x0;
-                fx[xb[u] >> 8] = x1;
-                fx[(xb[u] >> 8) + DP] = x1 * x1;
+                for (int u = 0; u < NXL; u++) {
+                    const double x0 = rx[u][0] - ol[xa[u] & 255u], x1 = rx[u][1] - ol[xb[u] & 255u];
+                    fx[xa[u] >> 8] = x0;
+                    fx[(xa[u] >> 8) + DP] = x0 * x0;
+                    fx[xb[u] >> 8] = x1;
+                    fx[(xb[u] >> 8) + DP] = x1 * x1;
+                }
+#pragma unroll
+                for (int u = 0; u < NPL; u++) ((v2d *)ps)[pcp[u]] = rp[u];
+#pragma unroll
+                for (int u = 0; u < NGL; u++) ((v2d *)gs)[pcg[u]] = rg[u];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
             }
+            unsigned smask_next;
+            if (MASKED) {
+                // the next occupied stage, in flight under this stage's MFMAs
+                cur = next_active(stg + 1, smask_next);
+                const long long nx = cur < s1 ? cur : stg;
+                fetch_gamma(nx, rg);
+                fetch(nx, cur < s1 ? smask_next : smask_cur);
+            } else {
+                // the next stage, in flight under this stage's MFMAs: its gammas arrived a stage ago
+                smask_next = state_mask(rgn);
+                fetch(stg + 1 < s1 ? stg + 1 : stg, smask_next);
 #pragma unroll
-            for (int u = 0; u < NPL; u++) ((v2d *)ps)[pcp[u]] = rp[u];
-#pragma unroll
-            for (int u = 0; u < NGL; u++) ((v2d *)gs)[pcg[u]] = rg[u];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
-            // the next stage, in flight under this stage's MFMAs: its gammas arrived a stage ago
-            const unsigned smask_next = state_mask(rgn);
-            fetch(stg + 1 < s1 ? stg + 1 : stg, smask_next);
-#pragma unroll
-            for (int u = 0; u < NGL; u++) rg[u] = rgn[u];
-            fetch_gamma(stg + 2 < s1 ? stg + 2 : (stg + 1 < s1 ? stg + 1 : stg), rgn);
+                for (int u = 0; u < NGL; u++) rg[u] = rgn[u];
+                fetch_gamma(stg + 2 < s1 ? stg + 2 : (stg + 1 < s1 ? stg + 1 : stg), rgn);
+            }
             // Gaussian tiles with a state of this stage's mask
             unsigned tact = 0;
 #pragma unroll
