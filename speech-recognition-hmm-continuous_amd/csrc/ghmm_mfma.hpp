@@ -838,9 +838,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
         // the x operands of this frame tile (x' and x'^2 of frame l & 15, k = 4s + (l >> 4))
-        // stay in registers for all of its Gaussian tiles where the epilogue leaves room
-        // (128 VGPRs = 4 waves per SIMD); otherwise they are re-read from the slab per tile
-        constexpr bool AREG = OUT != 2 || TPS > 1;
+        // stay in registers for all of its Gaussian tiles (168 VGPRs = 3 waves per SIMD; the
+        // log-b variant used to re-read them from the slab per tile: 1.19 -> 1.13 ms at
+        // configs[2] with them in registers; false = that variant, kept for measurements)
+        constexpr bool AREG = true;
         double a1[AREG ? Q : 1], a2[AREG ? Q : 1];
         if (AREG) {
 #pragma unroll
