@@ -15,3 +15,7 @@ model.init_from(corpus)
 t = time.perf_counter(); dm = model.init_from(corpus); td = time.perf_counter() - t
 err = max(np.abs(a - b).max() / np.abs(b).max() for a, b in zip(dm.arrays(), hm.arrays()))
 print(f"host init {th*1e3:.1f} ms, device init {td*1e3:.1f} ms, max rel diff {err:.2e}")
+ctx.set_option(G.OPT_TIMING, 1)
+ctx.kernel_times_reset()
+t = time.perf_counter(); model.init_from(corpus); td = time.perf_counter() - t
+print(f"with kernel timers: {td*1e3:.1f} ms;", {k: (round(v[0], 3), v[1]) for k, v in ctx.kernel_times().items() if v[1]})

@@ -1481,15 +1481,21 @@ extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c
             A[(size_t)i * N + j] = a;
         }
     const int64_t saved_kernels = ctx->kernels;
-    ctx->kernels = 1; // direct-form statistics for every pass
-    auto pass = [&](int n_cells) -> int {
+    // The k-means passes only need the cells' means (a plain quotient of sums) and the ORDER of
+    // their distortions: they run on the context's tier (matrix-core sums, 0.08 ms a pass).  The
+    // last pass gives the model's variances: direct-form statistics (x - mean)^2 on the vector
+    // ALU, like the reference takes them (0.7 ms).
+    auto pass = [&](int n_cells, bool exact) -> int {
+        ctx->kernels = exact ? 1 : saved_kernels;
         int r = ghmm_model_set(ctx, m, A.data(), cw.data(), cells.data(), ones.data(), det1.data());
         if (r) return r;
         {
             kscope ks(ctx, GHMM_K_PREPARE);
-            hipLaunchKernelGGL(k_init_classify, dim3((unsigned)((c->F + 255) / 256)), dim3(256), 0,
-                               ctx->stream, N, M, D, n_cells, c->U, c->F, c->X, c->off, m->mean,
-                               ctx->gamma, ctx->post);
+            int FR = IC_FRAMES; // frames per block: their copy in LDS stays under 48 KB
+            while (FR > 1 && (size_t)FR * (D | 1) * sizeof(double) > 48 * 1024) FR /= 2;
+            hipLaunchKernelGGL(k_init_classify, dim3((unsigned)((c->F + FR - 1) / FR)), dim3(256),
+                               (size_t)FR * (D | 1) * sizeof(double), ctx->stream, N, M, D, n_cells,
+                               c->U, c->F, FR, c->X, c->off, m->mean, ctx->gamma, ctx->post);
         }
         if ((r = launch_ok("k_init_classify")) || (r = run_accumulate(ctx, m, c, st))) return r;
         // a corpus sharded over ranks: the cell sums of all shards (every rank then does the
@@ -1526,7 +1532,7 @@ extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c
         return r;
     };
     // one cell per state: the mean of the state's frames
-    if ((rc = pass(1))) return finish(rc);
+    if ((rc = pass(1, false))) return finish(rc);
     for (int k = 0; k < N; k++)
         for (int l = 0; l < D; l++)
             cells[((size_t)k * M) * D + l] = num_mu[((size_t)k * M) * D + l] / num_c[(size_t)k * M];
@@ -1543,7 +1549,7 @@ extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c
         }
         n_cells = (2 * n_cells < M) ? 2 * n_cells : M;
         for (int it = 0; it < 3; it++) { // TF:1043
-            if ((rc = pass(n_cells))) return finish(rc);
+            if ((rc = pass(n_cells, false))) return finish(rc);
             for (int k = 0; k < N; k++) {
                 double *ck = cells.data() + (size_t)k * M * D;
                 for (int j = 0; j < n_cells; j++)
@@ -1559,7 +1565,7 @@ extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c
         }
     }
     // per-cell variance around the final means and cell weights (TF:883-933)
-    if ((rc = pass(M))) return finish(rc);
+    if ((rc = pass(M, true))) return finish(rc);
     std::vector<double> iv((size_t)G * D), dt((size_t)G);
     for (int k = 0; k < N; k++) {
         double dur = 0.0, sum = 0.0;

@@ -1258,46 +1258,98 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
 // ties), the mixture-statistics kernels give exactly what init_mix_mean / init_mix_param
 // accumulate: num_c = vectors per cell, num_mu = their sum, sum_d num_var = the cell's
 // distortion (and, in the last pass, the per-dimension squared deviations TF:883-891).
-// One thread per frame.
+// A block takes FR (<= IC_FRAMES) consecutive frames: coalesced copy into LDS, one thread per
+// frame for the classification, then the block writes the frames' one-hot rows as whole lines.
+constexpr int IC_FRAMES = 64;
 __global__ void __launch_bounds__(256)
-k_init_classify(int N, int M, int D, int n_cells, int U, long long F,
+k_init_classify(int N, int M, int D, int n_cells, int U, long long F, int FR,
                 const double *__restrict__ X, const long long *__restrict__ off,
                 const double *__restrict__ mean, double *__restrict__ gamma,
                 double *__restrict__ post)
 {
-    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    // utterance of this frame: last u with off[u] <= f
-    int lo = 0, hi = U - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (off[mid] <= f) lo = mid;
-        else hi = mid - 1;
-    }
-    const int T = (int)(off[lo + 1] - off[lo]), j = (int)(f - off[lo]);
-    // run k of an utterance of T frames: q = T/N frames, the first T%N runs one more
-    const int q = T / N, r = T % N;
-    int k;
-    if (j < r * (q + 1)) k = j / (q + 1);
-    else k = r + (q > 0 ? (j - r * (q + 1)) / q : 0);
-    const double *x = X + f * D;
-    double best = 1.0e20;
-    int cell = 0;
-    for (int c = 0; c < n_cells; c++) {
-        const double *mu = mean + ((size_t)k * M + c) * D;
-        double dist = 0.0;
-        for (int d = 0; d < D; d++) {
-            double aux = mu[d] - x[d];
-            dist += aux * aux;
-        }
-        if (dist < best) {
-            best = dist;
-            cell = c;
+    extern __shared__ double xs[]; // [FR][D | 1]
+    __shared__ int own_state[IC_FRAMES], own_gauss[IC_FRAMES];
+    const int tid = threadIdx.x, DS = D | 1, G = N * M;
+    const long long f0 = (long long)blockIdx.x * FR;
+    const int nf = (int)((F - f0) < FR ? (F - f0) : FR);
+    if (nf <= 0) return;
+    {
+        const double *src = X + f0 * D;
+        int r = tid / D, d = tid - r * D; // element tid of the block's nf x D slice, then + 256 per step
+        const int qs = 256 / D, rs = 256 - qs * D;
+        for (int e = tid; e < nf * D; e += 256) {
+            xs[r * DS + d] = src[e];
+            r += qs;
+            d += rs;
+            if (d >= D) {
+                d -= D;
+                r++;
+            }
         }
     }
-    double *g = gamma + f * N, *p = post + f * (size_t)N * M;
-    for (int i = 0; i < N; i++) g[i] = i == k ? 1.0 : 0.0;
-    for (int e = 0; e < N * M; e++) p[e] = e == k * M + cell ? 1.0 : 0.0;
+    __syncthreads();
+    if (tid < nf) {
+        const long long f = f0 + tid;
+        // utterance of this frame: last u with off[u] <= f
+        int lo = 0, hi = U - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= f) lo = mid;
+            else hi = mid - 1;
+        }
+        const int T = (int)(off[lo + 1] - off[lo]), j = (int)(f - off[lo]);
+        // run k of an utterance of T frames: q = T/N frames, the first T%N runs one more
+        const int q = T / N, r = T % N;
+        int k;
+        if (j < r * (q + 1)) k = j / (q + 1);
+        else k = r + (q > 0 ? (j - r * (q + 1)) / q : 0);
+        const double *x = xs + tid * DS;
+        double best = 1.0e20;
+        int cell = 0;
+        for (int c = 0; c < n_cells; c++) {
+            const double *mu = mean + ((size_t)k * M + c) * D;
+            double dist = 0.0;
+            for (int d = 0; d < D; d++) {
+                double aux = mu[d] - x[d];
+                dist += aux * aux;
+            }
+            if (dist < best) {
+                best = dist;
+                cell = c;
+            }
+        }
+        own_state[tid] = k;
+        own_gauss[tid] = k * M + cell;
+    }
+    __syncthreads();
+    {
+        double *g = gamma + f0 * N;
+        int r = tid / N, i = tid - r * N;
+        const int qs = 256 / N, rs = 256 - qs * N;
+        for (int e = tid; e < nf * N; e += 256) {
+            g[e] = i == own_state[r] ? 1.0 : 0.0;
+            r += qs;
+            i += rs;
+            if (i >= N) {
+                i -= N;
+                r++;
+            }
+        }
+    }
+    {
+        double *p = post + f0 * (size_t)G;
+        int r = tid / G, e1 = tid - r * G;
+        const int qs = 256 / G, rs = 256 - qs * G;
+        for (int e = tid; e < nf * G; e += 256) {
+            p[e] = e1 == own_gauss[r] ? 1.0 : 0.0;
+            r += qs;
+            e1 += rs;
+            if (e1 >= G) {
+                e1 -= G;
+                r++;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ viterbi
