@@ -867,9 +867,9 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 if ((shm >> (ct + tt)) & 1u) {
                     // this tile's own offset: x'' = x' - (offset - oglob), from the slab
                     const double *dq = dl + (ct + tt) * DP + kq;
-#pragma unroll 5
+#pragma unroll
                     for (int s = 0; s < Q; s++) {
-                        const double x1 = xr[4 * s] - dq[4 * s];
+                        const double x1 = (AREG ? a1[AREG ? s : 0] : xr[4 * s]) - dq[4 * s];
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[s * 64], x1, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(Q + s) * 64], x1 * x1, acc, 0, 0, 0);
                     }
