@@ -744,22 +744,59 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     };
     bool have = GHMM_EMS_PF && u < u1 && x16 && tf * 16 + 16 <= F; // xn holds the frames of tile tf (wave-uniform)
     if (have) loadx(tf);
-    for (int k = tid; k < tc * KS * 64; k += WV * WAVE)
-        Wl[(k & ~15) | slot_row(k & 15)] = Wm[(size_t)c0 * KS * 64 + k];
-    for (int k = tid; k < tc * 16; k += WV * WAVE) {
-        wkl[k] = wkp[c0 * 16 + k];
-        gml[k] = gmap[c0 * 16 + k];
+    {
+        // the chunk's B fragments, 16 bytes per lane, ALL loads in flight before the first store
+        // (a load-store loop of unknown trip count runs one L2 round trip per iteration while
+        // the whole chip waits for its first MFMA; asking for them before the work-share
+        // arithmetic above was measured and is not better)
+        constexpr int WPL = (GHMM_EMS_TC * KS * 32 + WV * WAVE - 1) / (WV * WAVE); // pairs per lane
+        const int npair = tc * KS * 32;
+        const v2d *wsrc = (const v2d *)(Wm + (size_t)c0 * KS * 64);
+        v2d wq[WPL];
+#pragma unroll
+        for (int q = 0; q < WPL; q++) {
+            const int pk = tid + q * WV * WAVE;
+            wq[q] = wsrc[pk < npair ? pk : npair - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < WPL; q++) {
+            const int pk = tid + q * WV * WAVE, k = 2 * pk;
+            if (pk < npair) {
+                Wl[(k & ~15) | slot_row(k & 15)] = wq[q][0];
+                Wl[(k & ~15) | slot_row((k & 15) + 1)] = wq[q][1];
+            }
+        }
     }
-    for (int k = tid; k < tc; k += WV * WAVE) {
-        tsl[k] = tshift[c0 + k];
-        // low bit: whole tile of consecutive Gaussians; bits 16..31: slots whose Gaussian is too
-        // ill-conditioned for the expanded form even around the tile's offset (condt)
-        unsigned bm = 0;
-        for (int pp = 0; pp < 16; pp++) bm |= (condt[(c0 + k) * 16 + pp] > COND_MAX ? 1u : 0u) << (16 + pp);
-        tfl[k] = (int)(bm | (tfull[c0 + k] != 0 ? 1u : 0u));
+    {
+        // the chunk's small tables the same way: unconditional loads at clamped indices first
+        // (tc * 16, tc, DP, tc * DP are all below the block's 768 threads), stores afterwards
+        const int n16 = tc * 16, nd = tc * DP;
+        const int k16 = tid < n16 ? tid : n16 - 1, kt = tid < tc ? tid : tc - 1;
+        const int kd = tid < D ? tid : D - 1, kdl = tid < nd ? tid : nd - 1;
+        const double wk_v = wkp[c0 * 16 + k16];
+        const int gm_v = gmap[c0 * 16 + k16];
+        const int ts_v = tshift[c0 + kt], tf_v = tfull[c0 + kt];
+        double cd_v[16];
+#pragma unroll
+        for (int pp = 0; pp < 16; pp++) cd_v[pp] = condt[(c0 + kt) * 16 + pp];
+        const double ol_v = oglob[kd];
+        const double dl_v = dtile[(size_t)c0 * DP + kdl];
+        if (tid < n16) {
+            wkl[tid] = wk_v;
+            gml[tid] = gm_v;
+        }
+        if (tid < tc) {
+            tsl[tid] = ts_v;
+            // low bit: whole tile of consecutive Gaussians; bits 16..31: slots whose Gaussian is too
+            // ill-conditioned for the expanded form even around the tile's offset (condt)
+            unsigned bm = 0;
+#pragma unroll
+            for (int pp = 0; pp < 16; pp++) bm |= (cd_v[pp] > COND_MAX ? 1u : 0u) << (16 + pp);
+            tfl[tid] = (int)(bm | (tf_v != 0 ? 1u : 0u));
+        }
+        if (tid < DP) ol[tid] = tid < D ? ol_v : 0.0;
+        if (tid < nd) dl[tid] = dl_v;
     }
-    for (int k = tid; k < DP; k += WV * WAVE) ol[k] = k < D ? oglob[k] : 0.0;
-    for (int k = tid; k < tc * DP; k += WV * WAVE) dl[k] = dtile[(size_t)c0 * DP + k];
     if (tid < 32) etab[tid] = EXP2_32[tid];
     __syncthreads();
     // per-tile flags of the chunk as bit masks in scalar registers (TC <= 32): no LDS round trip
