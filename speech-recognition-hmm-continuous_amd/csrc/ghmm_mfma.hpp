@@ -641,11 +641,12 @@ template <int MPL> __device__ inline double kq_max(double v)
 // 1 / s for the posteriors; 0 when s == 0 (TF:1773-1778).  Normal-range s: hardware seed + two
 // Newton steps (= the IEEE quotient's reciprocal in every case measured).  Tiny, huge, zero or
 // NaN s anywhere in the wave: the exact power-of-two rescale on a side path (wave-uniform branch).
-__device__ inline double recip_post(double s)
+__device__ inline double recip_post(double s, double &pre)
 {
     double rr = __builtin_amdgcn_rcp(s);
     rr = fma(rr, fma(-s, rr, 1.0), rr);
     rr = fma(rr, fma(-s, rr, 1.0), rr);
+    pre = 1.0;
     const bool odd = !(s >= 1.0e-290 && s <= 1.0e290);
     if (__any(odd)) {
         // (the empty asm keeps this a branch: folded into selects, the side path would cost every
@@ -656,7 +657,11 @@ __device__ inline double recip_post(double s)
         double r2 = __builtin_amdgcn_rcp(s2);
         r2 = fma(r2, fma(-s2, r2, 1.0), r2);
         r2 = fma(r2, fma(-s2, r2, 1.0), r2);
-        rr = odd ? (s != 0.0 ? r2 * sc : 0.0) : rr;
+        // a subnormal s: 1/s is beyond the largest double (the reference divides, TF:1776, and
+        // gets a finite share): the caller scales the density by `pre` first, then by 1/(s pre)
+        const bool sub = s < 0x1p-1020 && s > 0.0;
+        rr = odd ? (s != 0.0 ? (sub ? r2 : r2 * sc) : 0.0) : rr;
+        pre = sub ? sc : 1.0;
     }
     return rr;
 }
@@ -1037,14 +1042,25 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
             }
             if (OUT == 1) {
                 // gauss[i][j] /= b_i, 0 when b_i == 0 (TF:1773-1778)
-                double rr[NS];
+                double rr[NS], pre[NS];
+                bool subn = false;
 #pragma unroll
-                for (int v = 0; v < NS; v++) rr[v] = (GHMM_LAB & 8) ? sm[v] : recip_post(sm[v]);
+                for (int v = 0; v < NS; v++) {
+                    pre[v] = 1.0;
+                    rr[v] = (GHMM_LAB & 8) ? sm[v] : recip_post(sm[v], pre[v]);
+                    subn |= pre[v] != 1.0;
+                }
+                const bool fix = __any(subn); // some state's sum is subnormal (rare, wave-uniform)
 #pragma unroll
                 for (int tt = 0; tt < TPS; tt++) {
                     double pv[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) pv[r] = e[tt][r] * rr[r / GS];
+                    if (fix) {
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int r = 0; r < 4; r++) pv[r] = (e[tt][r] * pre[r / GS]) * rr[r / GS];
+                    }
                     if ((fum >> (ct + tt)) & 1u) {
                         // the lane's four posteriors are 32 contiguous, 16-byte aligned bytes
                         if (fok && !((GHMM_LAB & 2) && pv[0] + pv[1] + pv[2] + pv[3] != 12345.678)) {
