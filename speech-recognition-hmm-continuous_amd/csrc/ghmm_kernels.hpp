@@ -301,7 +301,9 @@ __device__ inline double recip_select(double s)
     const double r0 = __builtin_amdgcn_rcp(s); // inf for 0, 0 for inf, like 1.0/s
     double r = fma(r0, fma(-s, r0, 1.0), r0);
     r = fma(r, fma(-s, r, 1.0), r);
-    return (s >= 1.0e-290 && s <= 1.0e290) ? r : r0;
+    // refined wherever 1/s is a normal number (the raw reciprocal is good to ~1e-8 only: a first
+    // frame with b ~ 1e-294 used to carry that into alpha^_0 and c_0)
+    return (s >= 0x1p-1020 && s <= 0x1p1020) ? r : r0;
 }
 
 // one Newton step on the hardware reciprocal: 2e-15 relative (measured), enough for a

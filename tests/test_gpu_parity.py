@@ -841,7 +841,11 @@ def fuzz_shape(rng, wide):
     return N, M, D
 
 
-def fuzz_estep_case(G, ctx, seed, wide=False):
+class FuzzSkip(Exception):
+    """harsh fuzz case in which the reference itself has left the finite numbers"""
+
+
+def fuzz_estep_case(G, ctx, seed, wide=False, harsh=False):
     """E-step + M-step of the default tier against the oracle on one seeded random shape
     (1-20 states, 1-11 mixtures, 1-44 coefficients, dense or band-diagonal A, band 0..3; wide:
     fuzz_shape's larger shapes).  profiles/fuzz_oracle.py runs the same body over hundreds of
@@ -852,8 +856,16 @@ def fuzz_estep_case(G, ctx, seed, wide=False):
     lens = [int(x) for x in rng.integers(N, N + 120, size=int(rng.integers(1, 7)))]
     dense, delta = bool(rng.integers(0, 2)), int(rng.integers(0, 4))
     hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense, seed=seed,
-                             perturb=float(rng.choice([0.02, 0.1, 0.3])))
+                             perturb=float(rng.choice([0.6, 1.0] if harsh else [0.02, 0.1, 0.3])))
+    if harsh:
+        # a model far from its data, with sharpened Gaussians: densities that underflow, subnormal
+        # state sums, posteriors split between distant components (profiles/fuzz_oracle.py harsh)
+        k = float(rng.choice([1.0, 3.0, 9.0]))
+        hm.inv_var *= k
+        hm.det /= k ** D
     ref_stats, ref = O.estep(hm, X, lens, delta=delta)
+    if harsh and not (np.all(np.isfinite(ref["loglik"])) and np.all(np.isfinite(ref_stats))):
+        raise FuzzSkip()   # the reference's own NaN cascade: the documented deviations apply
     model, corpus = ctx.model(hm), ctx.corpus(X, lens)
     F = corpus.frames
     ctx.set_option(G.OPT_DELTA, delta)
@@ -932,6 +944,21 @@ def test_fuzz_wide_shapes_against_oracle(G, ctx, seed):
     """The same two bodies on shapes up to 64 states x 64 mixtures x 64 coefficients."""
     fuzz_estep_case(G, ctx, seed, wide=True)
     fuzz_viterbi_case(G, ctx, seed, wide=True)
+
+
+@pytest.mark.parametrize("seed,wide", [(12, False), (37, True), (1, False), (5, False), (6, False), (7, False),
+                                       (0, True), (1, True), (5, True), (6, True)])
+def test_fuzz_harsh_models_against_oracle(G, ctx, seed, wide):
+    """Models far from their data with sharpened Gaussians (densities near the underflow, subnormal
+    state sums).  12 and wide 37: a first frame whose densities are ~1e-294 — 1/b there must be
+    as exact as anywhere (the raw hardware reciprocal is good to 1e-8 only).  Cases in which the
+    reference itself leaves the finite numbers are not comparable, and Gaussians whose whole
+    occupancy is subnormal or below ~1e-150 get other parameters than the reference's (DESIGN
+    section 4): the seeds here are free of both."""
+    try:
+        fuzz_estep_case(G, ctx, seed, wide=wide, harsh=True)
+    except FuzzSkip:
+        pytest.skip("the reference's own statistics are not finite for this seed")
 
 
 # ------------------------------------------------------------------- boundary
