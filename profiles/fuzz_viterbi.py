@@ -1,7 +1,7 @@
 """Fuzz: Viterbi state sequences and forward scores of the product against the oracle's
 (oracle/ghmm_oracle.c) on seeded random shapes — the body is
 tests/test_gpu_parity.py:fuzz_viterbi_case (20 seeds of it run in the -m gpu suite).
-usage: fuzz_viterbi.py [n] [wide]"""
+usage: fuzz_viterbi.py [n] [wide] [harsh]"""
 import sys
 sys.path.insert(0, "tests")
 from _load import load_pkg
@@ -11,10 +11,11 @@ G = load_pkg().ghmm
 ctx = G.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 wide = "wide" in sys.argv[2:]
+harsh = "harsh" in sys.argv[2:]
 bad = utts = 0
 for seed in range(n):
     try:
-        utts += T.fuzz_viterbi_case(G, ctx, seed, wide=wide)
+        utts += T.fuzz_viterbi_case(G, ctx, seed, wide=wide, harsh=harsh)
     except AssertionError as e:
         bad += 1
         print(str(e)[:240])

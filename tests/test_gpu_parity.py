@@ -896,7 +896,7 @@ def fuzz_estep_case(G, ctx, seed, wide=False, harsh=False):
             o.close()
 
 
-def fuzz_viterbi_case(G, ctx, seed, wide=False):
+def fuzz_viterbi_case(G, ctx, seed, wide=False, harsh=False):
     """Viterbi state sequences (bit-identical) and forward scores against the oracle on one
     seeded random shape; profiles/fuzz_viterbi.py runs it over more seeds.  Returns the number
     of utterances checked."""
@@ -905,7 +905,11 @@ def fuzz_viterbi_case(G, ctx, seed, wide=False):
     lens = [int(x) for x in rng.integers(1, 150, size=int(rng.integers(1, 6)))]
     dense = bool(rng.integers(0, 2))
     hm, X, lens = synth_case(G, N, M, D, lens, dense_A=dense, seed=seed,
-                             perturb=float(rng.choice([0.02, 0.1, 0.3])))
+                             perturb=float(rng.choice([0.6, 1.0] if harsh else [0.02, 0.1, 0.3])))
+    if harsh:   # as in fuzz_estep_case: sharpened Gaussians far from the data
+        k = float(rng.choice([1.0, 3.0, 9.0]))
+        hm.inv_var *= k
+        hm.det /= k ** D
     model, corpus = ctx.model(hm), ctx.corpus(X, lens)
     try:
         path, score = ctx.viterbi(model, corpus)
