@@ -197,7 +197,8 @@ __device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool
     if (WANT_BETA && !(kappa > 0.0)) {
         // no path into the last state: rho from its own recursion, rho_t = c_t s_t rho_{t+1}
         rhon = su[T - 1];
-        for (int t = T - 2; t >= thi; t--) rhon = sbu[t] > 0.0 ? su[t] * rhon / sbu[t] : 0.0;
+        // (c_t s_t first: c_t rho_{t+1} alone can be beyond the largest double where rho_t is not)
+        for (int t = T - 2; t >= thi; t--) rhon = sbu[t] > 0.0 ? rhon * (su[t] / sbu[t]) : 0.0;
     }
     double dena = 0.0, denc = 0.0;
     double *pg = act ? gu + (size_t)(thi - 1) * N + i : sink;
@@ -235,7 +236,7 @@ __device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool
             if (kappa > 0.0) {
                 *pbe = bt * (ct * fac);
             } else {
-                if (t < T - 1) rhon = sbt > 0.0 ? ct * rhon / sbt : 0.0;
+                if (t < T - 1) rhon = sbt > 0.0 ? rhon * (ct / sbt) : 0.0;
                 *pbe = bt > 0.0 ? bt * rhon : 0.0; // (a zero stays zero when rho has overflowed)
             }
             pbe -= dn;
