@@ -3,7 +3,7 @@ bit-exact) followed by K fixed EM iterations on the GPU — against the oracle's
 corpora.  From that model components collapse onto single frames within a few iterations
 (variances at the 1e-5 floor), which is where the statistics classes, the per-tile offsets and the
 direct-form band of the emission kernel come into play.
-usage: fuzz_train.py [n_seeds] [iterations = 6]"""
+usage: fuzz_train.py [n_seeds] [iterations = 6] [big]   (big: 16 / 32 mixtures, several chunks of Gaussians)"""
 import sys
 import numpy as np
 sys.path.insert(0, "tests")
@@ -15,11 +15,16 @@ O = T.O
 ctx = G.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+big = "big" in sys.argv[3:]
 bad = skipped = floored_cases = 0
 for seed in range(n):
     rng = np.random.default_rng(61000 + seed)
     N = int(rng.integers(2, 11)); M = int(rng.choice([1, 2, 3, 4, 8])); D = int(rng.choice([5, 9, 13, 36, 39, 40]))
+    if big:
+        N = int(rng.integers(4, 17)); M = int(rng.choice([16, 32])); D = int(rng.choice([36, 39]))
     lens = np.asarray([int(x) for x in rng.integers(2 * N + 10, 2 * N + 90, size=int(rng.integers(3, 14)))], dtype=np.int32)
+    if big:   # enough frames for every cell of the initial codebook
+        lens = np.asarray([int(x) for x in rng.integers(3 * N * M // 4, N * M + 60, size=int(rng.integers(6, 14)))], dtype=np.int32)
     mean, std = G.synth_truth(N, M, D)
     X = G.synth_utterances(mean, std, lens, first_utt=seed)
     hm0 = G.HostModel.init_from(X, lens, N, M)
