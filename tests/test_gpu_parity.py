@@ -959,6 +959,29 @@ def test_fuzz_wide_shapes_against_oracle(G, ctx, seed):
     fuzz_viterbi_case(G, ctx, seed, wide=True)
 
 
+def test_long_utterances_against_oracle(G, ctx):
+    """Utterances of thousands of frames (the reference caps them at 500, TF:44; the C ABI does
+    not): recursions, statistics and Viterbi paths against the oracle."""
+    hm, X, lens = synth_case(G, 10, 8, 39, [5000, 1203, 17, 2500])
+    ref_stats, ref = O.estep(hm, X, lens)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    ctx.estep(model, corpus, stats)
+    F = corpus.frames
+    assert_close(ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ref["loglik"], what="loglik")
+    assert_frames(ctx.fetch(G.BUF_ALPHA, (F, 10)), ref["alpha"], "alpha")
+    assert_frames(ctx.fetch(G.BUF_BETA, (F, 10)), ref["beta"], "beta")
+    assert_close(stats.download(), ref_stats, what="stats")
+    path, _ = ctx.viterbi(model, corpus)
+    o = 0
+    for u, Tn in enumerate(lens):
+        p, _ = O.viterbi(hm, X[o:o + Tn])
+        assert np.array_equal(path[o:o + Tn], p), f"utterance {u}: path differs"
+        o += Tn
+    for obj in (model, corpus, stats):
+        obj.close()
+
+
 @pytest.mark.parametrize("seed", [68, 253, 437])
 def test_fuzz_short_utterances_against_oracle(G, ctx, seed):
     """Utterances of 1 .. N + 30 frames, some shorter than the model (no path into the last state:
