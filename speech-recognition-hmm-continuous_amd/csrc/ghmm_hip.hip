@@ -108,7 +108,8 @@ struct ghmm_model {
     double *A = nullptr, *c = nullptr, *mean = nullptr, *inv_var = nullptr, *det = nullptr;
     double *wk = nullptr, *logwk = nullptr, *logA = nullptr;
     // matrix-core tier (ghmm_mfma.hpp): padded geometry and B fragments
-    int Mp = 0, NT = 0, DP = 0, TC = 0, TCs = 0, tps = 1; // TCs: tiles per chunk of k_emission_sched
+    int Mp = 0, NT = 0, DP = 0, TC = 0, tps = 1;
+    int TCs[3] = {0, 0, 0}; // tiles per chunk of k_emission_sched, per output mode
     size_t em_lds = 0;
     bool mfma_ok = false;
     double *Wm = nullptr, *offs = nullptr, *wkp = nullptr, *logwkp = nullptr, *condp = nullptr;
@@ -512,13 +513,14 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
         int TC = tcmax / m->tps * m->tps;
         if (TC > m->NT) TC = m->NT;
         m->TC = TC;
-        // the scheduled kernel (12 slabs of DP + 2 doubles): as many whole states per chunk as
-        // fit beside them, up to 8 tiles — every chunk stages the frames again
-        {
-            int tcs = GHMM_EMS_TC / m->tps * m->tps;
-            while (tcs > m->tps && ems_lds_bytes(tcs, m->DP, ems_waves(Mp)) > 159 * 1024) tcs -= m->tps;
+        // the scheduled kernel: as many whole states per chunk as fit beside its slabs (none in
+        // the b-only variant) — every chunk reads the frames again
+        for (int out = 0; out < 3; out++) {
+            int tcs = ems_tc_cap(out) / m->tps * m->tps;
+            while (tcs > m->tps && ems_lds_bytes(tcs, m->DP, ems_waves(Mp, out), out) > 159 * 1024) tcs -= m->tps;
+            if (tcs < m->tps) tcs = m->tps;
             if (tcs > m->NT) tcs = m->NT;
-            m->TCs = tcs > TC ? tcs : TC;
+            m->TCs[out] = tcs;
         }
         m->em_lds = (size_t)TC * per_tile + slabs;
         m->mfma_ok = TC >= m->tps && TC > 0 && m->em_lds <= 150 * 1024 && 16 * m->D <= 64 * EM_XR;
@@ -917,12 +919,13 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         // frames where its density is not 0.
         int rc;
         const long long ntf = (c->F + 15) / 16;
-        const int chunks = (m->NT + m->TCs - 1) / m->TCs;
-        const int wv = ems_waves(m->Mp);
-        const size_t lds_s = ems_lds_bytes(m->TCs, m->DP, wv);
+        const int po = mode == 2 ? 2 : (post ? 1 : 0);
+        const int tcs = m->TCs[po];
+        const int chunks = (m->NT + tcs - 1) / tcs;
+        const int wv = ems_waves(m->Mp, po);
+        const size_t lds_s = ems_lds_bytes(tcs, m->DP, wv, po);
         long long gxs = (ntf + wv - 1) / wv;
         if (gxs > ctx->cus) gxs = ctx->cus;
-        const int po = mode == 2 ? 2 : (post ? 1 : 0);
         const double *wk = mode == 2 ? m->logwkp : m->wkp; // OUT = 2 adds log wk to the exponents
         kscope ks(ctx, GHMM_K_EMISSION);
 #define GHMM_EMS(MP, PO)                                                                          \
@@ -930,7 +933,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, PO>))) return rc;         \
         hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3((unsigned)(wv * WAVE)), lds_s, ctx->stream, m->N, m->M, m->D, m->NT, \
-                           m->TCs, c->F, c->X, m->Wm, m->oglob, wk, m->gmap, ctx->b, post, m->dtile, \
+                           tcs, c->F, c->X, m->Wm, m->oglob, wk, m->gmap, ctx->b, post, m->dtile, \
                            m->tshift, m->tfull, m->condt, m->mean, m->inv_var);                   \
     } while (0)
 #define GHMM_EMS3(MP)                                                                             \

@@ -535,10 +535,27 @@ constexpr int EMS_WAVES = 16;
 #ifndef GHMM_EMS_W32
 #define GHMM_EMS_W32 12 // the same for states of 32 / 64 mixtures
 #endif
-#ifndef GHMM_EMS_TC
-#define GHMM_EMS_TC 8 // most Gaussian tiles per chunk (each chunk stages the frames again)
+// How a frame tile's operands reach the MFMA lanes, per output mode (measured in one session,
+// profiles/r2_lab_emission_direct.txt): through a per-wave LDS slab (16-byte coalesced loads,
+// 12 waves of 168 registers) for the trainer's and the log-b variants; for the b-only variant
+// (recogniser, 2 000-state configuration) straight from HBM into the lanes' registers — ten
+// 8-byte loads per lane from one row pointer — which needs no slab (14 Gaussian tiles per chunk
+// instead of 8) and fits 128 registers, i.e. 16 waves.  Bit mask over OUT: 1 = OUT 0.
+#ifndef GHMM_EMS_DIRECT
+#define GHMM_EMS_DIRECT 1
 #endif
-__host__ __device__ constexpr int ems_waves(int MP) { return MP >= 32 ? GHMM_EMS_W32 : GHMM_EMS_W; }
+__host__ __device__ constexpr bool ems_direct(int OUT) { return ((GHMM_EMS_DIRECT >> OUT) & 1) != 0; }
+#ifndef GHMM_EMS_TC
+#define GHMM_EMS_TC 8 // most Gaussian tiles per chunk with the slab (each chunk reads the frames again)
+#endif
+#ifndef GHMM_EMS_TCD
+#define GHMM_EMS_TCD 14 // the same without it
+#endif
+__host__ __device__ constexpr int ems_tc_cap(int OUT) { return ems_direct(OUT) ? GHMM_EMS_TCD : GHMM_EMS_TC; }
+__host__ __device__ constexpr int ems_waves(int MP, int OUT)
+{
+    return MP >= 32 ? GHMM_EMS_W32 : (ems_direct(OUT) ? 16 : GHMM_EMS_W);
+}
 
 // 2^(j/32), j = 0..31, correctly rounded
 __device__ const double EXP2_32[32] = {
@@ -671,10 +688,10 @@ __device__ inline double recip_post(double s, double &pre)
 __device__ __host__ inline int slot_row(int p) { return (p >> 2) + 4 * (p & 3); }
 
 // LDS bytes of k_emission_sched for a chunk of TC tiles
-__host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves)
+__host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves, int OUT)
 {
     const int KS = DP / 2, XS = DP + 2;
-    return (size_t)TC * KS * 64 * 8 + (size_t)waves * 16 * XS * 8 + (size_t)DP * 8 + // (see the kernel)
+    return (size_t)TC * KS * 64 * 8 + (ems_direct(OUT) ? 0 : (size_t)waves * 16 * XS * 8) + (size_t)DP * 8 + // (see the kernel)
            (size_t)TC * 16 * 8 + (size_t)TC * DP * 8 + 32 * 8 + (size_t)TC * 16 * 4 + (size_t)TC * 4 * 2 + 64;
 }
 
@@ -684,7 +701,7 @@ __host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves)
 // (slots beyond COND_MAX are re-evaluated in direct form where their density is not 0).  tfull[tile]: the tile's 16 slots are 16 consecutive real Gaussians
 // starting at an even index and G is even (its posteriors go out as aligned 16-byte stores).
 template <int KS, int MP, int OUT>
-__global__ void __launch_bounds__(ems_waves(MP) * WAVE)
+__global__ void __launch_bounds__(ems_waves(MP, OUT) * WAVE)
 k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double *__restrict__ X,
                  const double *__restrict__ Wm, const double *__restrict__ oglob,
                  const double *__restrict__ wkp, const int *__restrict__ gmap,
@@ -696,15 +713,16 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     extern __shared__ double lds[];
     // slab row stride 2 * odd doubles: the 32 lanes of a ds_read_b64 group (16 frames x 2
     // k-columns) then fall on 32 different bank pairs
-    constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 2, WV = ems_waves(MP);
+    constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 2, WV = ems_waves(MP, OUT);
+    constexpr bool DIRECT = ems_direct(OUT);
     constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : MP == 16 ? 4 : MP == 32 ? 5 : 6;
     constexpr int MPL = MP < 16 ? MP : 16, TPS = MP <= 16 ? 1 : MP / 16;
     constexpr int NS = MPL == 1 ? 4 : (MPL == 2 ? 2 : 1); // states per lane
     constexpr int GS = 4 / NS;                            // a state's registers in the lane
     const int G = N * M;
     double *Wl = lds;                                // [TC][KS][64], Gaussians on their MFMA rows
-    double *xl = Wl + (size_t)TC * KS * 64;          // [WV][16][XS]
-    double *ol = xl + (size_t)WV * 16 * XS;   // [DP]
+    double *xl = Wl + (size_t)TC * KS * 64;          // [WV][16][XS] (slab variant only)
+    double *ol = xl + (DIRECT ? 0 : (size_t)WV * 16 * XS); // [DP]
     double *wkl = ol + DP;                           // [TC][16] by slot
     // tiles that hold a variance-floored component take that component's mean as their offset:
     // dl = offset - oglob (subtracted from the x operand of that tile), tsl = "shifted"
@@ -747,14 +765,31 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
             xn[u2] = src[pc];
         }
     };
-    bool have = GHMM_EMS_PF && u < u1 && x16 && tf * 16 + 16 <= F; // xn holds the frames of tile tf (wave-uniform)
-    if (have) loadx(tf);
+    // DIRECT: lane (frame j = l & 15, kq = l >> 4) needs x[f0 + j][4 s + kq], s = 0 .. Q-1: ten
+    // 8-byte loads from one per-lane row pointer with immediate offsets (rows past the corpus
+    // clamp to its last frame; the last k-step, whose columns can lie beyond D, reads a clamped
+    // column).  No slab, no alignment condition, one path for whole and ragged tiles.
+    double xd[Q];
+    const int kl = 4 * (Q - 1) + kq < D ? 4 * (Q - 1) + kq : D - 1; // column of the last k-step, clamped
+    auto loadd = [&](long long tfx) {
+        long long fr2 = tfx * 16 + j;
+        fr2 = fr2 < F ? fr2 : F - 1;
+        const double *row = X + fr2 * D;
+#pragma unroll
+        for (int s2 = 0; s2 < Q - 1; s2++) xd[s2] = row[4 * s2 + kq];
+        xd[Q - 1] = row[kl];
+    };
+    bool have = GHMM_EMS_PF && u < u1 && (DIRECT || (x16 && tf * 16 + 16 <= F)); // xn / xd hold the frames of tile tf (wave-uniform)
+    if (have) {
+        if (DIRECT) loadd(tf);
+        else loadx(tf);
+    }
     {
         // the chunk's B fragments, 16 bytes per lane, ALL loads in flight before the first store
         // (a load-store loop of unknown trip count runs one L2 round trip per iteration while
         // the whole chip waits for its first MFMA; asking for them before the work-share
         // arithmetic above was measured and is not better)
-        constexpr int WPL = (GHMM_EMS_TC * KS * 32 + WV * WAVE - 1) / (WV * WAVE); // pairs per lane
+        constexpr int WPL = (ems_tc_cap(OUT) * KS * 32 + WV * WAVE - 1) / (WV * WAVE); // pairs per lane
         const int npair = tc * KS * 32;
         const v2d *wsrc = (const v2d *)(Wm + (size_t)c0 * KS * 64);
         v2d wq[WPL];
@@ -816,19 +851,36 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     fum = (unsigned)__builtin_amdgcn_readfirstlane((int)fum);
     bdm = (unsigned)__builtin_amdgcn_readfirstlane((int)bdm); // tiles that hold such a slot
     double *xw = xl + w * 16 * XS;
-    // constant columns of the slab: the 1 at column D, zeros beyond
-    for (int k = l; k < 16 * (XS - D); k += WAVE) {
-        const int r = k / (XS - D), e = k - r * (XS - D);
-        xw[r * XS + D + e] = e == 0 ? 1.0 : 0.0;
+    if (!DIRECT) {
+        // constant columns of the slab: the 1 at column D, zeros beyond
+        for (int k = l; k < 16 * (XS - D); k += WAVE) {
+            const int r = k / (XS - D), e = k - r * (XS - D);
+            xw[r * XS + D + e] = e == 0 ? 1.0 : 0.0;
+        }
     }
     const double *xr = xw + j * XS + kq; // x operand: frame l&15, k = 4s + (l>>4)
+    // DIRECT: the last k-step's column 4 (Q-1) + kq is a coefficient, the constant 1 (column D) or padding
+    const int klast = 4 * (Q - 1) + kq;
+    const bool last_real = klast < D;
+    const double last_const = klast == D ? 1.0 : 0.0;
     if (GHMM_LAB & 32) return; // (lab: block set-up only)
     for (; u < u1; tf++, g0 = 0) {
         const long long f0 = tf * 16;
         const int g1 = (u1 - u) < (long long)(ng - g0) ? g0 + (int)(u1 - u) : ng;
         u += g1 - g0;
         const bool full = f0 + 16 <= F; // wave-uniform
-        if (full && x16) {
+        double a1[Q], a2[Q];
+        if (DIRECT) {
+            if (!have) loadd(tf);
+#pragma unroll
+            for (int s2 = 0; s2 < Q - 1; s2++) a1[s2] = xd[s2] - ol[4 * s2 + kq];
+            a1[Q - 1] = last_real ? xd[Q - 1] - ol[kl] : last_const;
+#pragma unroll
+            for (int s2 = 0; s2 < Q; s2++) a2[s2] = a1[s2] * a1[s2];
+            // the wave's next frame tile, under this tile's matrix and vector work
+            have = GHMM_EMS_PF && u < u1 && f0 + 16 < F;
+            if (have) loadd(tf + 1);
+        } else if (full && x16) {
             // the wave's 16 x D frame tile is contiguous in HBM and starts on a 16-byte
             // boundary (f0 is a multiple of 16)
             if (!have) loadx(tf);
@@ -878,14 +930,13 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
         // the x operands of this frame tile (x' and x'^2 of frame l & 15, k = 4s + (l >> 4))
         // stay in registers for all of its Gaussian tiles (168 VGPRs = 3 waves per SIMD; the
         // log-b variant used to re-read them from the slab per tile: 1.19 -> 1.13 ms at
-        // configs[2] with them in registers; false = that variant, kept for measurements)
+        // configs[2] with them in registers)
         constexpr bool AREG = true;
-        double a1[AREG ? Q : 1], a2[AREG ? Q : 1];
-        if (AREG) {
+        if (!DIRECT) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
 #pragma unroll
             for (int s = 0; s < Q; s++) {
                 a1[s] = xr[4 * s];
