@@ -516,8 +516,8 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
         // the scheduled kernel: as many whole states per chunk as fit beside its slabs (none in
         // the b-only variant) — every chunk reads the frames again
         for (int out = 0; out < 3; out++) {
-            int tcs = ems_tc_cap(out) / m->tps * m->tps;
-            while (tcs > m->tps && ems_lds_bytes(tcs, m->DP, ems_waves(Mp, out), out) > 159 * 1024) tcs -= m->tps;
+            int tcs = ems_tc_cap(Mp, out) / m->tps * m->tps;
+            while (tcs > m->tps && ems_lds_bytes(tcs, m->DP, ems_waves(Mp, out), Mp, out) > 159 * 1024) tcs -= m->tps;
             if (tcs < m->tps) tcs = m->tps;
             if (tcs > m->NT) tcs = m->NT;
             m->TCs[out] = tcs;
@@ -923,7 +923,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const int tcs = m->TCs[po];
         const int chunks = (m->NT + tcs - 1) / tcs;
         const int wv = ems_waves(m->Mp, po);
-        const size_t lds_s = ems_lds_bytes(tcs, m->DP, wv, po);
+        const size_t lds_s = ems_lds_bytes(tcs, m->DP, wv, m->Mp, po);
         long long gxs = (ntf + wv - 1) / wv;
         if (gxs > ctx->cus) gxs = ctx->cus;
         const double *wk = mode == 2 ? m->logwkp : m->wkp; // OUT = 2 adds log wk to the exponents

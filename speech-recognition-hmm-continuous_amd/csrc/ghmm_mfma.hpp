@@ -540,21 +540,26 @@ constexpr int EMS_WAVES = 16;
 // 12 waves of 168 registers) for the trainer's and the log-b variants; for the b-only variant
 // (recogniser, 2 000-state configuration) straight from HBM into the lanes' registers — ten
 // 8-byte loads per lane from one row pointer — which needs no slab (14 Gaussian tiles per chunk
-// instead of 8) and fits 128 registers, i.e. 16 waves.  Bit mask over OUT: 1 = OUT 0.
+// instead of 8) and fits 128 registers, i.e. 16 waves.  States of 32 / 64 mixtures (12 waves either
+// way) gain 2.7 % from the larger chunks in the trainer's variant too.  Bit mask: bit OUT for
+// <= 16 mixtures, bit 3 + OUT for 32 / 64.
 #ifndef GHMM_EMS_DIRECT
-#define GHMM_EMS_DIRECT 1
+#define GHMM_EMS_DIRECT (1 | (1 << 3) | (1 << 4))
 #endif
-__host__ __device__ constexpr bool ems_direct(int OUT) { return ((GHMM_EMS_DIRECT >> OUT) & 1) != 0; }
+__host__ __device__ constexpr bool ems_direct(int MP, int OUT)
+{
+    return ((GHMM_EMS_DIRECT >> (OUT + (MP >= 32 ? 3 : 0))) & 1) != 0;
+}
 #ifndef GHMM_EMS_TC
 #define GHMM_EMS_TC 8 // most Gaussian tiles per chunk with the slab (each chunk reads the frames again)
 #endif
 #ifndef GHMM_EMS_TCD
 #define GHMM_EMS_TCD 14 // the same without it
 #endif
-__host__ __device__ constexpr int ems_tc_cap(int OUT) { return ems_direct(OUT) ? GHMM_EMS_TCD : GHMM_EMS_TC; }
+__host__ __device__ constexpr int ems_tc_cap(int MP, int OUT) { return ems_direct(MP, OUT) ? GHMM_EMS_TCD : GHMM_EMS_TC; }
 __host__ __device__ constexpr int ems_waves(int MP, int OUT)
 {
-    return MP >= 32 ? GHMM_EMS_W32 : (ems_direct(OUT) ? 16 : GHMM_EMS_W);
+    return MP >= 32 ? GHMM_EMS_W32 : (ems_direct(MP, OUT) ? 16 : GHMM_EMS_W);
 }
 
 // 2^(j/32), j = 0..31, correctly rounded
@@ -688,10 +693,10 @@ __device__ inline double recip_post(double s, double &pre)
 __device__ __host__ inline int slot_row(int p) { return (p >> 2) + 4 * (p & 3); }
 
 // LDS bytes of k_emission_sched for a chunk of TC tiles
-__host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves, int OUT)
+__host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves, int MP, int OUT)
 {
     const int KS = DP / 2, XS = DP + 2;
-    return (size_t)TC * KS * 64 * 8 + (ems_direct(OUT) ? 0 : (size_t)waves * 16 * XS * 8) + (size_t)DP * 8 + // (see the kernel)
+    return (size_t)TC * KS * 64 * 8 + (ems_direct(MP, OUT) ? 0 : (size_t)waves * 16 * XS * 8) + (size_t)DP * 8 + // (see the kernel)
            (size_t)TC * 16 * 8 + (size_t)TC * DP * 8 + 32 * 8 + (size_t)TC * 16 * 4 + (size_t)TC * 4 * 2 + 64;
 }
 
@@ -714,7 +719,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     // slab row stride 2 * odd doubles: the 32 lanes of a ds_read_b64 group (16 frames x 2
     // k-columns) then fall on 32 different bank pairs
     constexpr int DP = 2 * KS, Q = KS / 2, XS = DP + 2, WV = ems_waves(MP, OUT);
-    constexpr bool DIRECT = ems_direct(OUT);
+    constexpr bool DIRECT = ems_direct(MP, OUT);
     constexpr int LOGMP = MP == 1 ? 0 : MP == 2 ? 1 : MP == 4 ? 2 : MP == 8 ? 3 : MP == 16 ? 4 : MP == 32 ? 5 : 6;
     constexpr int MPL = MP < 16 ? MP : 16, TPS = MP <= 16 ? 1 : MP / 16;
     constexpr int NS = MPL == 1 ? 4 : (MPL == 2 ? 2 : 1); // states per lane
@@ -789,7 +794,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
         // (a load-store loop of unknown trip count runs one L2 round trip per iteration while
         // the whole chip waits for its first MFMA; asking for them before the work-share
         // arithmetic above was measured and is not better)
-        constexpr int WPL = (ems_tc_cap(OUT) * KS * 32 + WV * WAVE - 1) / (WV * WAVE); // pairs per lane
+        constexpr int WPL = (ems_tc_cap(MP, OUT) * KS * 32 + WV * WAVE - 1) / (WV * WAVE); // pairs per lane
         const int npair = tc * KS * 32;
         const v2d *wsrc = (const v2d *)(Wm + (size_t)c0 * KS * 64);
         v2d wq[WPL];
