@@ -208,6 +208,8 @@ def side_measurements(G, em, ctx, torch, dev, mean, std, start, corpus, kavg):
     # (1) EM from ghmm_model_init's model on the bench corpus: iterations 3-10, the regime the
     # real trainer runs in (variance-floored components collapse onto single frames)
     model = ctx.model(start)
+    model.init_from(corpus)      # (the first call also sizes its workspace and loads its kernels)
+    ctx.sync()
     t0 = time.perf_counter()
     model.init_from(corpus)
     ctx.sync()
