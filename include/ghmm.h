@@ -71,8 +71,11 @@ enum {
     GHMM_OPT_DELTA = 1,
     /* 0 (default): emission densities in the reference's linear domain
      *    (exp() underflows exactly where the reference's does, TF:1821-1836);
-     * 1: per-frame max-normalised densities (finite where the reference is not;
-     *    the log of the normaliser is added back into the log-likelihood). */
+     * 1: per-frame max-normalised densities (the log of the normaliser is added back
+     *    into the log-likelihood): finite where the reference's densities underflow as a
+     *    whole frame.  It is still a linear-domain recursion: a frame whose REACHABLE states
+     *    lie more than ~308 decades below its best state ends the utterance as in the
+     *    reference (profiles/fuzz_robust.py). */
     GHMM_OPT_ROBUST = 2,
     /* 0 auto, 1 vector-ALU kernels and the reference's order of the recursions (calc_alpha,
      * then calc_beta scaled by its c_t, one pass each), 2 MFMA (f64 16x16x4) kernels and the
