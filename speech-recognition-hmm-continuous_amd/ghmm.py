@@ -291,13 +291,42 @@ def synth_truth(N, M, D, seed=SYNTH_SEED):
     return mean, std
 
 
-def synth_utterances(mean, std, lens, first_utt=0, seed=SYNTH_SEED):
+def synth_utterances(mean, std, lens, first_utt=0, seed=SYNTH_SEED, threads=1):
+    """Utterance u depends only on (seed, first_utt + u) (ghmm_synth.c), so `threads` > 1 deals
+    contiguous blocks of utterances to host threads (the C call releases the GIL): same bytes."""
     lib = host_lib()
     N, M, D = mean.shape
     lens = np.ascontiguousarray(lens, dtype=np.int32)
     X = np.empty((int(lens.sum()), D))
-    _check(lib.ghmm_synth_utterances(seed, N, M, D, _d(mean), _d(std), first_utt, len(lens),
-                                     lens.ctypes.data_as(_ip), _d(X)), lib)
+    U = len(lens)
+    threads = max(1, min(int(threads), U))
+
+    def block(lo, hi, f0):
+        ln = np.ascontiguousarray(lens[lo:hi])
+        _check(lib.ghmm_synth_utterances(seed, N, M, D, _d(mean), _d(std), first_utt + lo, hi - lo,
+                                         ln.ctypes.data_as(_ip), _d(X[f0:])), lib)
+
+    if threads == 1:
+        block(0, U, 0)
+        return X
+    import threading
+    off = np.concatenate([[0], np.cumsum(lens, dtype=np.int64)])
+    cuts = [U * k // threads for k in range(threads + 1)]
+    errs = []
+
+    def run(lo, hi):
+        try:
+            block(lo, hi, int(off[lo]))
+        except BaseException as e:   # noqa: BLE001 - re-raised below on the caller's thread
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(cuts[k], cuts[k + 1])) for k in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
     return X
 
 
@@ -469,13 +498,14 @@ class Model:
         _check(self.ctx.lib.ghmm_model_set(self.ctx.h, self.h, *(_d(x) for x in hm.arrays())),
                self.ctx.lib)
 
-    def init_from(self, corpus, comm=None):
-        """creating_initial_model (TF:732) on the device; returns the model as HostModel.
+    def init_from(self, corpus, comm=None, fetch=True):
+        """creating_initial_model (TF:732) on the device; returns the model as HostModel
+        (fetch=False: leaves it on the device, nothing is downloaded).
         `comm`: the corpus is one rank's shard, the k-means sums are all-reduced."""
         _check(self.ctx.lib.ghmm_model_init_comm(self.ctx.h, self.h, corpus.h,
                                                  comm.h if comm is not None else None),
                self.ctx.lib)
-        return self.get()
+        return self.get() if fetch else None
 
     def get(self):
         N, M, D = self.N, self.M, self.D

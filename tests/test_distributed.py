@@ -94,3 +94,61 @@ def test_two_ranks_equal_one(G):
     # both ranks hold the same model bit for bit (same reduced statistics, same M-step)
     for a, b in zip(res[0][1], res[1][1]):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ self-launch of the ranks
+
+_RANK_SCRIPT = """\
+import json, os, sys
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+fail = len(sys.argv) > 2 and int(sys.argv[2]) == r
+if r == 0:
+    print(json.dumps({"n_gpus": w, "argv": sys.argv[1:], "local": os.environ["LOCAL_RANK"],
+                      "master": os.environ["MASTER_ADDR"]}), flush=True)
+sys.exit(3 if fail else 0)
+"""
+
+
+def test_self_launch_starts_the_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher environment: launch.py
+    starts N child ranks through torch.distributed.run on 127.0.0.1, passes rank 0's one line
+    through and returns the children's code; a failing rank makes it non-zero; an inherited
+    launcher environment does not leak into the children."""
+    import io
+    import json
+    L = load_pkg().launch
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    assert not L.under_launcher({})
+    assert L.under_launcher({"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    cmd = L.launch_command("bench.py", ["--gpus", "4"], 4, 1234, python="python3")
+    assert cmd[:3] == ["python3", "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-3:] == ["bench.py", "--gpus", "4"]
+    out = io.StringIO()
+    env = dict(os.environ, RANK="7", WORLD_SIZE="9", LOCAL_RANK="7", MASTER_PORT="1")
+    rc = L.self_launch(str(script), ["--gpus"], 3, env=env, stdout=out)
+    assert rc == 0
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {"n_gpus": 3, "argv": ["--gpus"], "local": "0", "master": "127.0.0.1"}
+    out = io.StringIO()
+    assert L.self_launch(str(script), ["x", "1"], 2, stdout=out) != 0
+
+
+def test_bench_self_launches_when_gpus_exceeds_one(tmp_path):
+    """bench.py itself: with --gpus 2 and no launcher environment it must become the launcher
+    (and not raise "launch with torch.distributed.run" as in round 2).  There is no GPU here, so
+    the ranks stop at bench.py's own "needs an MI355X" exit: what is checked is that they were
+    started as 2 ranks (that message, rc != 0, no round-2 message)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""       # the same outcome on a box that has a GPU
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--spinup", "0"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0
+    assert "needs an MI355X" in p.stderr and "launch with torch.distributed.run" not in p.stderr

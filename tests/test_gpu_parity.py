@@ -1464,3 +1464,35 @@ def test_emission_frames_on_an_odd_8_byte_boundary(G, ctx):
     assert_close(stats.download(), ref, what="statistics from unaligned frames")
     for o_ in (model, corpus, stats):
         o_.close()
+
+
+# ------------------------------------------------- bench.py --gpus 2, self-launched, one GPU
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 ...` exactly as the driver types it, no launcher environment:
+    bench.py starts its two ranks itself (launch.py), here both on device 0 with gloo standing in
+    for RCCL (a one-GPU box cannot hold a two-rank RCCL communicator), and rank 0 prints the one
+    JSON line with n_gpus = ranks = 2, the all-reduce timed, and BASELINE configs[3]'s shape
+    (64 mixtures, fixed 10 iterations, scaled down to 40 utterances per rank) as extras.config4."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(GHMM_FORCE_DEVICE="0", GHMM_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--spinup", "0", "--utts", "64", "--frames", "120",
+                        "--config4", "on", "--config4-utts", "40"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["dist_backend"] == "gloo"
+    assert rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["frames_per_step"] == 2 * 64 * 120
+    assert rec["value"] > 0 and rec["value_cold"] > 0 and rec["allreduce_ms"] > 0
+    c4 = rec["extras"]["config4"]
+    assert c4["iterations"] == 10 and c4["checks_ok"] is True
+    assert np.isfinite(rec["loglik_per_frame"])
