@@ -176,6 +176,10 @@ int ghmm_stats_wrap(ghmm_ctx *ctx, int N, int M, int D, double *dev_ptr, ghmm_st
 void ghmm_stats_destroy(ghmm_ctx *ctx, ghmm_stats *s);
 double *ghmm_stats_device_ptr(ghmm_stats *s);
 int ghmm_stats_download(ghmm_ctx *ctx, ghmm_stats *s, double *host);
+/* the two numbers the EM driver's stopping rule reads every iteration (TF:318-325):
+ * out[0] = sum of log P over the utterances (`probab`), out[1] = utterance count
+ * (`exemplar_number`) — a 16-byte download instead of the whole vector */
+int ghmm_stats_loglik(ghmm_ctx *ctx, ghmm_stats *s, double out[2]);
 int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *host);
 
 /* ---------------------------------------------- the path, one row at a time */
@@ -273,9 +277,17 @@ int ghmm_comm_unique_id(void *id_bytes);
 int ghmm_comm_create(ghmm_ctx *ctx, const void *id_bytes, int rank, int world, ghmm_comm **out);
 /* the same with the id passed through a file: rank 0 creates the id and writes `path`
  * (atomically, via rename), the other ranks wait up to timeout_s for it to appear; rank 0
- * removes the file once every rank has joined.  `path` must be unique per job. */
+ * removes the file once every rank has joined (ghmm_rendezvous_file below).  A `path` per job is
+ * good practice, no longer a requirement. */
 int ghmm_comm_create_file(ghmm_ctx *ctx, const char *path, int rank, int world, double timeout_s,
                           ghmm_comm **out);
+/* the id exchange of ghmm_comm_create_file on its own — host code, no GPU, no RCCL (also in
+ * libghmm_host.so): rank 0 passes its id IN and returns once every other rank has taken it;
+ * the other ranks receive it in id_bytes.  Ranks announce themselves in `path`.join.<rank>
+ * with a fresh nonce that the published `path` echoes, so a file left by an earlier job is
+ * never taken for this job's id; a rank 0 that starts late is waited for; every wait ends
+ * after timeout_s with GHMM_ERR_IO.  world = 1: returns at once, nothing is written. */
+int ghmm_rendezvous_file(const char *path, int rank, int world, double timeout_s, void *id_bytes);
 void ghmm_comm_destroy(ghmm_comm *comm);
 int ghmm_comm_rank(const ghmm_comm *comm);
 int ghmm_comm_size(const ghmm_comm *comm);

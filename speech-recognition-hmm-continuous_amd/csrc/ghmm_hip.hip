@@ -809,6 +809,17 @@ extern "C" int ghmm_stats_download(ghmm_ctx *ctx, ghmm_stats *s, double *host)
     return GHMM_OK;
 }
 
+extern "C" int ghmm_stats_loglik(ghmm_ctx *ctx, ghmm_stats *s, double out[2])
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ARG_CHECK(s && out, "null argument");
+    // loglik and n_utt are the last two doubles of the vector (layout in ghmm.h)
+    HIP_TRY(hipMemcpyAsync(out, s->v + (s->n - 2), 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GHMM_OK;
+}
+
 extern "C" int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *host)
 {
     int rc = use(ctx);
@@ -1983,37 +1994,11 @@ extern "C" int ghmm_comm_create_file(ghmm_ctx *ctx, const char *path, int rank, 
     ARG_CHECK(path && *path && out, "bad arguments");
     unsigned char id[GHMM_COMM_ID_BYTES];
     int rc;
-    if (rank == 0) {
-        if ((rc = ghmm_comm_unique_id(id))) return rc;
-        std::vector<char> tmp(strlen(path) + 32);
-        snprintf(tmp.data(), tmp.size(), "%s.tmp.%ld", path, (long)getpid());
-        FILE *f = fopen(tmp.data(), "wb");
-        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp.data(), path) != 0) {
-            ghmm_set_error("cannot publish the communicator id in %s", path);
-            return GHMM_ERR_IO;
-        }
-    } else {
-        const double step = 0.01;
-        double waited = 0.0;
-        for (;;) {
-            struct stat st;
-            FILE *f = (stat(path, &st) == 0 && st.st_size == (off_t)sizeof id) ? fopen(path, "rb") : nullptr;
-            if (f) {
-                const size_t n = fread(id, 1, sizeof id, f);
-                fclose(f);
-                if (n == sizeof id) break;
-            }
-            if (waited >= timeout_s) {
-                ghmm_set_error("rank %d: no communicator id in %s after %.0f s", rank, path, timeout_s);
-                return GHMM_ERR_IO;
-            }
-            usleep((useconds_t)(step * 1e6));
-            waited += step;
-        }
-    }
-    rc = ghmm_comm_create(ctx, id, rank, world, out);
-    if (rank == 0) (void)unlink(path); // every rank has joined (or the job has failed)
-    return rc;
+    if (rank == 0 && (rc = ghmm_comm_unique_id(id))) return rc;
+    // the id travels by the host-only file protocol of ghmm_rendezvous.c (nonce handshake,
+    // bounded waits, rank 0 removes the file once every rank holds the id)
+    if ((rc = ghmm_rendezvous_file(path, rank, world, timeout_s, id))) return rc;
+    return ghmm_comm_create(ctx, id, rank, world, out);
 }
 
 extern "C" void ghmm_comm_destroy(ghmm_comm *cm)

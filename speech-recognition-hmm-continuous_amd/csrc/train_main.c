@@ -267,9 +267,7 @@ int main(int argc, char **argv)
         snprintf(hm[p].word, sizeof hm[p].word, "%s", word);
         if ((rc = ghmm_stats_create(ctx, N, M[p], D[p], &stats[p]))) die("statistics", rc);
     }
-    size_t ns = ghmm_stats_len(N, M[0], D[0]);
-    double *sv = (double *)malloc(ns * sizeof(double));
-    if (!sv) die("memory", GHMM_ERR_ALLOC);
+    double lp[2] = {0.0, 0.0}; /* probab and exemplar_number of the pass (TF:318-320) */
 
     printf("\r\nCreating HMM using Forward-Backward algorithm (Baum-Welch)");
     double probab, old_probab = 1.0, variation; /* TF:151 */
@@ -281,8 +279,9 @@ int main(int argc, char **argv)
         /* the one exchange of the iteration: sum of the accumulators over ranks (one vector per stream) */
         for (int p = 0; comm && p < P; p++)
             if ((rc = ghmm_stats_allreduce(ctx, stats[p], comm))) die("all-reduce", rc);
-        if ((rc = ghmm_stats_download(ctx, stats[0], sv))) die("E-step", rc);
-        probab = sv[ns - 2];
+        /* the stopping rule reads two numbers: 16 bytes come back, not the whole vector */
+        if ((rc = ghmm_stats_loglik(ctx, stats[0], lp))) die("E-step", rc);
+        probab = lp[0];
         printf("\r\nEnding training sequence");
         variation = fabs((old_probab - probab) / old_probab);
         printf("\r\nVerifying Probability: %f > Threshold: %f", variation, THRESHOLD);
@@ -294,7 +293,7 @@ int main(int argc, char **argv)
         }
     } while (variation > THRESHOLD);
     printf("\r\nFinal Probability = %f\r\n\r\n", variation);
-    if (comm) n_utt = (int)sv[ns - 1]; /* exemplars of all ranks (TF:320, summed) */
+    if (comm) n_utt = (int)lp[1]; /* exemplars of all ranks (TF:320, summed) */
     probab /= (double)n_utt;
 
     for (int p = 0; p < P; p++)
@@ -349,7 +348,6 @@ done:
         free(X[p]);
     }
     ghmm_ctx_destroy(ctx);
-    free(sv);
     free(len);
     return 0;
 }

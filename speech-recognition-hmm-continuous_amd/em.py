@@ -87,4 +87,4 @@ class HipBackend:
         return self._t
 
     def loglik(self):
-        return float(self.stats.download()[-2])
+        return self.stats.loglik()[0]

@@ -82,6 +82,7 @@ SYMBOLS = {
     "ghmm_stats_device_ptr": (_vp, [_vp], True),
     "ghmm_stats_download": (C.c_int, [_vp, _vp, _dp], True),
     "ghmm_stats_upload": (C.c_int, [_vp, _vp, _dp], True),
+    "ghmm_stats_loglik": (C.c_int, [_vp, _vp, _dp], True),
     "ghmm_emission": (C.c_int, [_vp, _vp, _vp, C.c_int], True),
     "ghmm_forward": (C.c_int, [_vp, _vp, _vp], True),
     "ghmm_backward": (C.c_int, [_vp, _vp, _vp], True),
@@ -101,6 +102,7 @@ SYMBOLS = {
     "ghmm_perfil_stat": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)], False),
     "ghmm_shard_balanced": (C.c_int, [_ip, C.c_int, C.c_int, C.c_int, _ip, C.POINTER(C.c_int)],
                             False),
+    "ghmm_rendezvous_file": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_double, _vp], False),
     "ghmm_free": (None, [_vp], False),
     "ghmm_host_model_alloc": (C.c_int, [C.POINTER(HostModelStruct), C.c_int, C.c_int, C.c_int],
                               False),
@@ -338,6 +340,14 @@ def synth_start_model(mean, std, perturb=0.05, seed=SYNTH_SEED):
     _check(lib.ghmm_synth_start_model(seed, N, M, D, _d(mean), _d(std), perturb, _d(A), _d(c),
                                       _d(mu), _d(iv), _d(det)), lib)
     return HostModel(A, c, mu, iv, det, "synth")
+
+
+def rendezvous_file(path, rank, world, timeout_s=120.0, id_bytes=None):
+    """ghmm_rendezvous_file: rank 0 passes the 128-byte id, the other ranks get it back."""
+    lib = host_lib()
+    buf = C.create_string_buffer(id_bytes if id_bytes is not None else b"", 128)
+    _check(lib.ghmm_rendezvous_file(os.fsencode(path), rank, world, float(timeout_s), buf), lib)
+    return buf.raw
 
 
 def stats_len(N, M, D):
@@ -598,6 +608,12 @@ class Stats:
         out = np.empty(self.n, dtype=np.float64)
         _check(self.ctx.lib.ghmm_stats_download(self.ctx.h, self.h, _d(out)), self.ctx.lib)
         return out
+
+    def loglik(self):
+        """(sum of log P, utterance count): the 16 bytes the stopping rule reads (TF:318-325)"""
+        out = np.empty(2, dtype=np.float64)
+        _check(self.ctx.lib.ghmm_stats_loglik(self.ctx.h, self.h, _d(out)), self.ctx.lib)
+        return float(out[0]), float(out[1])
 
     def upload(self, v):
         v = _f64(v)

@@ -201,3 +201,96 @@ def test_perfil_stat_reads_header_and_size(G, tmp_path):
     assert D == 9 and T == len(G.perfil_read(os.path.join(GOLDEN, "perfil", "mean_vc_186_f_03_ap_0225.perfil")))
     with pytest.raises(G.GhmmError):
         G.perfil_stat(os.path.join(str(tmp_path), "missing.perfil"))
+
+
+# ------------------------------------------- rendezvous file protocol (ghmm_rendezvous.c)
+
+def _rdv_proc(path, rank, world, timeout, id_bytes, delay, q):
+    import time
+    from _load import ghmm
+    G = ghmm()
+    time.sleep(delay)
+    try:
+        q.put((rank, G.rendezvous_file(path, rank, world, timeout, id_bytes), None))
+    except G.GhmmError as e:
+        q.put((rank, None, e.code))
+
+
+def _rdv_threads(G, path, world, timeout, ident, delays=None, absent=()):
+    """one thread per rank (the C call releases the GIL, keeps no global state)"""
+    import threading
+    import time
+    res = {}
+
+    def run(r):
+        time.sleep((delays or {}).get(r, 0.0))
+        try:
+            res[r] = G.rendezvous_file(path, r, world, timeout, ident if r == 0 else None)
+        except G.GhmmError as e:
+            res[r] = e.code
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world) if r not in absent]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return res
+
+
+def test_rendezvous_three_processes_and_a_late_rank_zero(G, tmp_path):
+    """The id exchange of ghmm_comm_create_file with more than one rank, as
+    separate PROCESSES: every rank obtains rank 0's 128 bytes, a rank 0 that starts late is
+    waited for, and nothing is left behind."""
+    import multiprocessing as mp
+    ident = bytes(range(128))
+    path = str(tmp_path / "job.id")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdv_proc, args=(path, r, 3, 30.0, ident if r == 0 else None,
+                                                 0.6 if r == 0 else 0.0, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1, 2]
+    assert all(r[1] == ident and r[2] is None for r in res)
+    assert os.listdir(tmp_path) == []
+
+
+def test_rendezvous_timeouts_and_stale_files(G, tmp_path):
+    ident = bytes((7 * k + 3) % 256 for k in range(128))
+    # world = 1: nothing to exchange, nothing written
+    path = str(tmp_path / "one.id")
+    assert G.rendezvous_file(path, 0, 1, 1.0, ident) == ident and os.listdir(tmp_path) == []
+    # rank 0 never comes: the other rank gives up with GHMM_ERR_IO and takes its join file away
+    path = str(tmp_path / "a.id")
+    assert _rdv_threads(G, path, 2, 0.3, ident, absent=(0,)) == {1: G.ERR_IO}
+    assert os.listdir(tmp_path) == []
+    # rank 2 never comes: the id is published only once EVERY rank has announced itself, so
+    # ranks 0 and 1 both give up (nobody is left holding an id of a job that cannot start)
+    path = str(tmp_path / "b.id")
+    res = _rdv_threads(G, path, 3, 0.4, ident, absent=(2,))
+    assert res == {0: G.ERR_IO, 1: G.ERR_IO}
+    assert os.listdir(tmp_path) == []
+    # a published file left behind by an EARLIER job (same path, same size, valid magic, old
+    # nonces, another id) is not taken for this job's id
+    path = str(tmp_path / "c.id")
+    old_id = bytes(128)
+    rec = np.array([0x31305644524d4847, 3, 111, 222], dtype=np.uint64).tobytes() + old_id
+    open(path, "wb").write(rec)
+    res = _rdv_threads(G, path, 3, 10.0, ident, delays={0: 0.3})
+    assert res == {0: ident, 1: ident, 2: ident}
+    assert os.listdir(tmp_path) == []
+    # a JOIN file left behind by a crashed rank 1 of an earlier job: rank 0 first publishes
+    # with that stale nonce, the real rank 1 arrives later with a fresh one and is served
+    path = str(tmp_path / "d.id")
+    open(path + ".join.1", "wb").write(np.array([0x31305644524d4847, 1, 999], dtype=np.uint64).tobytes())
+    res = _rdv_threads(G, path, 2, 10.0, ident, delays={1: 0.3})
+    assert res == {0: ident, 1: ident}
+    assert os.listdir(tmp_path) == []
+    # bad arguments
+    for args in (("", 0, 2), (path, 2, 2), (path, -1, 2), (path, 0, 0)):
+        with pytest.raises(G.GhmmError) as e:
+            G.rendezvous_file(args[0], args[1], args[2], 0.1, ident)
+        assert e.value.code == G.ERR_ARG
