@@ -45,7 +45,7 @@ enum {
     GHMM_ERR_ALLOC = 2,       /* host or device allocation failed */
     GHMM_ERR_HIP = 3,         /* a HIP runtime call failed */
     GHMM_ERR_NODEVICE = 4,    /* no usable gfx950 device */
-    GHMM_ERR_UNSUPPORTED = 5, /* valid request outside what is built (e.g. P > 1) */
+    GHMM_ERR_UNSUPPORTED = 5, /* valid request outside what is built (e.g. more than 64 states in the recursions) */
     GHMM_ERR_IO = 6,          /* file could not be opened / read / written */
     GHMM_ERR_FORMAT = 7       /* file content is not a .perfil / .hmm */
 };
@@ -89,7 +89,12 @@ enum {
     /* compute units the one-block-per-CU kernels size their grids for (0 = all of the
      * device's, the default): for a caller whose stream is restricted to part of the device
      * (hipExtStreamCreateWithCUMask) */
-    GHMM_OPT_CUS = 6
+    GHMM_OPT_CUS = 6,
+    /* read-only (ghmm_ctx_get_option; synchronises the stream): utterances the last gamma / xi
+     * pass of the default tier took again in the reference's own order of operations — no path
+     * into the last state, or forward and backward mass more than 200 decades apart at some
+     * frame (ghmm_pair.hpp, RANGE).  0 on data the model fits. */
+    GHMM_OPT_REFORDER_COUNT = 7
 };
 int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value);
 int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value);

@@ -68,6 +68,12 @@ struct ghmm_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     double *wrow = nullptr, *sb = nullptr, *lpart = nullptr, *logk = nullptr;
     size_t cap_wrow = 0, cap_sb = 0, cap_lpart = 0, cap_logk = 0;
+    // utterances k_combine hands to k_backward_fix (ghmm_pair.hpp, RANGE): per-utterance marks
+    // stamped with the pass number, the list, and two counters used alternately (the fix-up
+    // kernel of pass n zeroes the counter of pass n + 1)
+    int *fix_mark = nullptr, *fix_list = nullptr, *fix_cnt = nullptr;
+    size_t cap_fix_mark = 0, cap_fix_list = 0;
+    int fix_stamp = 0;
     bool loglik_pieces = false; // log P of the last E-step is in lpart / logk, loglik[] not assembled
     bool own_bwd_done = false; // k_scan_pair ran the backward direction for the current alpha
     bool beta_valid = false;   // ctx->beta holds the reference's beta^
@@ -338,7 +344,8 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
                     ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb,
-                    ctx->lpart,   ctx->logk,      ctx->b_stream,  ctx->smask};
+                    ctx->lpart,   ctx->logk,      ctx->b_stream,  ctx->smask,
+                    ctx->fix_mark, ctx->fix_list, ctx->fix_cnt};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (double *p : ctx->post_s)
@@ -407,6 +414,16 @@ extern "C" int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value)
     case GHMM_OPT_TIMING: *value = ctx->timing; break;
     case GHMM_OPT_PARTIALS: *value = ctx->partials; break;
     case GHMM_OPT_CUS: *value = ctx->cus; break;
+    case GHMM_OPT_REFORDER_COUNT: {
+        int n = 0, rc = use(ctx);
+        if (rc) return rc;
+        if (ctx->fix_cnt && ctx->fix_stamp > 0) {
+            HIP_TRY(hipMemcpyAsync(&n, ctx->fix_cnt + (ctx->fix_stamp & 1), sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        *value = n;
+        break;
+    }
     default:
         ghmm_set_error("unknown option %d", option);
         return GHMM_ERR_ARG;
@@ -899,6 +916,16 @@ static int ws_fb(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
     if ((rc = dev_grow(&ctx->part_xi, &ctx->cap_pxi, UN * (MAX_DELTA + 1)))) return rc;
     if ((rc = dev_grow(&ctx->part_dena, &ctx->cap_pdena, UN))) return rc;
     if ((rc = dev_grow(&ctx->part_denc, &ctx->cap_pdenc, UN))) return rc;
+    if ((size_t)c->U > ctx->cap_fix_mark) {
+        if ((rc = dev_grow(&ctx->fix_mark, &ctx->cap_fix_mark, (size_t)c->U))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->fix_mark, 0, ctx->cap_fix_mark * sizeof(int), ctx->stream));
+        ctx->fix_stamp = 0; // (stamps start at 1: a zeroed mark never equals one)
+    }
+    if ((rc = dev_grow(&ctx->fix_list, &ctx->cap_fix_list, (size_t)c->U))) return rc;
+    if (!ctx->fix_cnt) {
+        if ((rc = dev_alloc(&ctx->fix_cnt, 2))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->fix_cnt, 0, 2 * sizeof(int), ctx->stream));
+    }
     return GHMM_OK;
 }
 
@@ -1067,6 +1094,25 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_b
     return launch_ok("k_forward");
 }
 
+// The utterances the pass before it listed (none on data a model fits), again, whole, in the
+// reference's own order of operations with its dense inner loops: one small launch that leaves
+// at once on an empty list.  spu = partial-sum slots per utterance of that pass.
+static int run_backward_fix(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int L, unsigned blocks, int spu,
+                            const double *sinv)
+{
+    const unsigned fb = blocks < 256u ? blocks : 256u;
+    int *cnt = ctx->fix_cnt + (ctx->fix_stamp & 1), *nxt = ctx->fix_cnt + ((ctx->fix_stamp + 1) & 1);
+    if (L == 16)
+        hipLaunchKernelGGL(k_backward_fix<16>, dim3(fb), dim3(WAVE), 0, ctx->stream, m->N, c->U, (int)ctx->delta,
+                           m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta, ctx->gamma, ctx->part_xi,
+                           ctx->part_dena, ctx->part_denc, ctx->sink, cnt, ctx->fix_list, nxt, spu, sinv);
+    else
+        hipLaunchKernelGGL(k_backward_fix<64>, dim3(fb), dim3(WAVE), 0, ctx->stream, m->N, c->U, (int)ctx->delta,
+                           m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta, ctx->gamma, ctx->part_xi,
+                           ctx->part_dena, ctx->part_denc, ctx->sink, cnt, ctx->fix_list, nxt, spu, sinv);
+    return launch_ok("k_backward_fix");
+}
+
 // gamma, the xi / den partial sums and (want_beta) the reference's beta^
 static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_beta = true)
 {
@@ -1098,10 +1144,16 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
                        (int)ctx->delta, m->A, c->off, ctx->alpha, ctx->scale, ctx->wrow, ctx->sb, \
                        ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, \
                        ctx->robust ? ctx->lognorm : (const double *)nullptr,                     \
-                       ctx->loglik_pieces ? ctx->lpart : (double *)nullptr, ctx->logk, c->order)
+                       ctx->loglik_pieces ? ctx->lpart : (double *)nullptr, ctx->logk, c->order,  \
+                       ctx->fix_mark, ctx->fix_stamp, ctx->fix_cnt + (ctx->fix_stamp & 1), ctx->fix_list)
             // the M-step keeps a band-diagonal A band-diagonal as long as it re-estimates
             // no transition beyond i -> i + 1
             const bool band2 = m->banded && ctx->delta <= 1;
+            if (++ctx->fix_stamp == 0x7fffffff) { // (2^31 passes: start the marks over)
+                HIP_TRY(hipMemsetAsync(ctx->fix_mark, 0, ctx->cap_fix_mark * sizeof(int), ctx->stream));
+                HIP_TRY(hipMemsetAsync(ctx->fix_cnt, 0, 2 * sizeof(int), ctx->stream));
+                ctx->fix_stamp = 1;
+            }
             if (L == 16 && band2) {
                 if (want_beta) GHMM_COMBINE(16, true, false);
                 else GHMM_COMBINE(16, false, false);
@@ -1112,19 +1164,26 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
                 if (want_beta) GHMM_COMBINE(64, true, true);
                 else GHMM_COMBINE(64, false, true);
             }
+            if ((rc = run_backward_fix(ctx, m, c, L, blocks, CB_CH, nullptr))) return rc;
             ctx->beta_valid = want_beta;
             ctx->last_m = m;
             ctx->last_c = c;
             ctx->slots = c->U * CB_CH;
         } else {
+            ++ctx->fix_stamp; // (no marks on this tier: a wave lists each of its utterances once)
+            int *cnt = ctx->fix_cnt + (ctx->fix_stamp & 1);
             if (L == 16)
                 hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                    (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order);
+                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order,
+                                   cnt, ctx->fix_list);
             else
                 hipLaunchKernelGGL(k_backward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                    (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order);
+                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order,
+                                   cnt, ctx->fix_list);
+            // utterances whose band-only update met an overflowed beta^: again, dense (TF:1493-1510)
+            if ((rc = run_backward_fix(ctx, m, c, L, blocks, 1, ctx->sinv))) return rc;
             ctx->beta_valid = true;
             ctx->slots = c->U;
         }

@@ -575,6 +575,7 @@ k_forward_multi(int U, int NS, long long F, const fwd_model *__restrict__ tab,
 // kept by the forward pass instead of a division.
 template <int L, bool BANDED> struct bwd_state {
     double be, a_self, a_next, dena, denc;
+    bool wild = false; // a beta^ that is inf or NaN (see backward_run's return value)
     double arow[BANDED ? 1 : L];
     double aband[MAX_DELTA + 1], xi[MAX_DELTA + 1];
     int N, delta;
@@ -603,6 +604,7 @@ template <int L, bool BANDED> struct bwd_state {
                 xi[o] += (i + o < N) ? al * wj : 0.0;
             }
         be = aux * c;
+        if (BANDED) wild |= !(fabs(be) < INFINITY);
         const double g = (al * sv) * be;
         *pbe = be;
         *pg = g;
@@ -610,8 +612,12 @@ template <int L, bool BANDED> struct bwd_state {
     }
 };
 
+// Returns (BANDED only) whether a beta^ left the finite numbers: next to an overflowed beta^ the
+// reference's dense inner loop (TF:1493-1510) multiplies inf by every a_ij = 0 of the row and
+// turns the whole row NaN, which the band-only update does not reproduce; the caller then takes
+// the utterance again with the dense form (k_backward_fix).
 template <int L, bool BANDED>
-__device__ __forceinline__ void backward_run(int N, int T, int delta, int i, bool act, int u,
+__device__ __forceinline__ bool backward_run(int N, int T, int delta, int i, bool act, int u,
                                     const double *__restrict__ A, const double *__restrict__ bu,
                                     const double *__restrict__ au, const double *__restrict__ su,
                                     const double *__restrict__ si, double *__restrict__ beu,
@@ -644,7 +650,8 @@ __device__ __forceinline__ void backward_run(int N, int T, int delta, int i, boo
     {
         const double cT = su[T - 1];
         st.be = (i == N - 1) ? 1.0 * cT : 0.0;
-        const double g = (act ? pa0[(size_t)(T - 1) * dn] : 0.0) * st.be * si[T - 1];
+        // (si == nullptr, k_backward_fix: the paired launch keeps no 1/c_t; it is divided out here)
+        const double g = (act ? pa0[(size_t)(T - 1) * dn] : 0.0) * st.be * (si ? si[T - 1] : 1.0 / cT);
         *pbe = st.be;
         *pg = g;
         st.denc = g; // gamma_{T-1}: in den_c (t < T, TF:1660) but not in den_a (t < T-1, TF:1618)
@@ -658,7 +665,7 @@ __device__ __forceinline__ void backward_run(int N, int T, int delta, int i, boo
         qb[k] = pb0[(f + 1 < (size_t)T ? f + 1 : (size_t)T - 1) * dn];
         qa[k] = pa0[f * dn];
         qc[k] = su[f];
-        qs[k] = si[f];
+        qs[k] = si ? si[f] : 1.0 / su[f];
     }
     pbe -= dn; pg -= dn;
     for (; t - PF + 1 >= 0; t -= PF) {
@@ -669,7 +676,7 @@ __device__ __forceinline__ void backward_run(int N, int T, int delta, int i, boo
             nb[k] = pb0[(f + 1 < (size_t)T ? f + 1 : (size_t)T - 1) * dn];
             na[k] = pa0[f * dn];
             nc[k] = su[f];
-            ns[k] = si[f];
+            ns[k] = si ? si[f] : 1.0 / su[f];
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {
@@ -694,6 +701,7 @@ __device__ __forceinline__ void backward_run(int N, int T, int delta, int i, boo
         part_dena[pden_at(u, i, S)] = st.dena;
         part_denc[pden_at(u, i, S)] = st.dena + st.denc;
     }
+    return st.wild;
 }
 
 template <int L>
@@ -703,7 +711,8 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
            const double *__restrict__ scale, const double *__restrict__ sinv,
            double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ part_xi,
            double *__restrict__ part_dena, double *__restrict__ part_denc,
-           double *__restrict__ sink, const int *__restrict__ order)
+           double *__restrict__ sink, const int *__restrict__ order, int *__restrict__ fix_cnt,
+           int *__restrict__ fix_list)
 {
     const int slot = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
@@ -725,11 +734,13 @@ k_backward(int N, int U, int delta, const double *__restrict__ A, const double *
         offband |= act && (A[i * N + j] != 0.0 && j != i && j != i + 1);
     const bool banded = !__any(offband);
     double *snk = wave_sink(sink);
-    if (banded)
-        backward_run<L, true>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
-                              sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
-                              part_denc, snk, U);
-    else
+    if (banded) {
+        const bool wild = backward_run<L, true>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
+                                                sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
+                                                part_denc, snk, U);
+        // (the ballot covers the wave's other utterances too: they are only taken twice)
+        if (__any(wild) && i == 0) fix_list[atomicAdd(fix_cnt, 1)] = u;
+    } else
         backward_run<L, false>(N, T, delta, i, act, u, A, b + f0 * N, alpha + f0 * N, scale + f0,
                                sinv + f0, beta + f0 * N, gamma + f0 * N, part_xi, part_dena,
                                part_denc, snk, U);

@@ -3,9 +3,9 @@
 // The reference's calc_beta (TF:1463-1516) multiplies every step by the forward pass's c_t, so
 // it can only start when calc_alpha has finished; both are serial in t and bound by one
 // utterance's dependent chain, with 1 000 utterances on a quarter of the chip's SIMDs.  Here
-// the backward recursion carries its OWN normaliser,
+// the backward recursion carries its OWN normaliser, an exact power of two,
 //     W_t(i)    = b_i(t+1) beta~_{t+1}(i)                       (kept, row t)
-//     v_t       = A W_t,   s_t = sum_i v_t(i),   beta~_t = v_t / s_t     (1/s_t kept)
+//     v_t       = A W_t,   beta~_t = v_t 2^(e_t),  e_t = BT_K - exponent(sum_i v_t(i))   (2^(e_t) kept)
 //     beta~_{T-1} = e_{N-1}                                      (final-state constraint, TF:1484-1490)
 // so that it needs nothing from the forward pass and runs beside it in the same launch
 // (k_scan_pair, blockIdx.y = direction).  beta~_t is the reference's beta^_t up to a factor
@@ -13,12 +13,21 @@
 //     sum_i alpha^_t(i) beta^_t(i) = c_t kappa,  kappa = alpha^_{T-1}(N-1)      (induction on TF:1507)
 //     =>  rho_t = c_t kappa / D_t,   D_t = sum_i alpha^_t(i) beta~_t(i)
 // k_combine then forms, for every frame independently (chunks of an utterance in parallel),
-//     gamma_t(i) = alpha^_t(i) beta^_t(i) / c_t = kappa alpha^_t(i) beta~_t(i) / D_t     (TF:1655-1660)
-//     xi_t(i,j)  = alpha^_t(i) a_ij b_j(t+1) beta^_{t+1}(j) = alpha^_t(i) a_ij W_t(j) rho_{t+1}   (TF:1601-1614)
-// and, when asked for it, beta^_t = rho_t beta~_t.  An utterance that cannot end in the last
-// state (kappa = 0: shorter than the model, or numerically dead) has gamma = xi = 0 here as in
-// the reference, whose alpha^ beta^ products are all 0 then; its beta^ is rebuilt from
-// rho_t = c_t s_t rho_{t+1} instead.
+//     gamma_t(i) = alpha^_t(i) beta^_t(i) / c_t = (alpha^_t(i) beta~_t(i) / D_t) kappa     (TF:1655-1660)
+//     xi_t(i,j)  = alpha^_t(i) a_ij b_j(t+1) beta^_{t+1}(j) = (alpha^_t(i) a_ij W_t(j) c_{t+1} / D_{t+1}) kappa
+// (TF:1601-1614) and, when asked for it, beta^_t = rho_t beta~_t.
+//
+// RANGE.  Rows of beta~ sum to about 2^BT_K (BT_K = 680, 5e204), not to 1: a component survives
+// down to 2^-1022 absolutely = 1e-512 of its row's largest, and since the scale is a power of two
+// the normalisation rounds nothing.  The reference keeps beta^_t(i) = rho_t beta~_t(i) down to
+// 2^-1022 as well, i.e. it sees FURTHER below the row's largest only where rho_t > 2^BT_K.  Such
+// an utterance (forward and backward mass more than 200 decades apart at some frame: start
+// models far from their data), one whose D_t leaves the numbers altogether, and one with no path
+// into the last state (kappa = 0: shorter than the model, or numerically dead; the reference's
+// beta^ and NaN artefacts are what its own order of operations makes them) is put on a list by
+// k_combine and taken again, whole, by k_backward_fix in the reference's order of operations
+// (calc_beta scaled by c_t, dense inner loops as at TF:1493-1510).  Round 2 normalised the rows
+// to a sum of 1 (v_t / s_t): 17 of 607 harsh shapes then lost components the reference keeps.
 #pragma once
 #include "ghmm_kernels.hpp"
 
@@ -29,6 +38,9 @@ namespace ghmm {
 #endif
 constexpr int CB_CH = GHMM_CB_CH; // chunks of an utterance handled by different groups of k_combine
 constexpr int CB_PF = 4; // frames of operands read ahead in k_combine (x 2 register sets x 4 operands)
+// rows of beta~ are scaled to a sum in [2^BT_K, 2^(BT_K+1)): W = b beta~ stays finite for densities
+// up to 1e100 (a 39-d Gaussian at the 1e-5 variance floor peaks at 1e82) and keeps 512 decades
+constexpr int BT_K = 680;
 
 template <int L, bool BANDED>
 __device__ __forceinline__ void backward_own_run(int N, int T, int i, bool act, const double *__restrict__ A,
@@ -44,11 +56,11 @@ __device__ __forceinline__ void backward_own_run(int N, int T, int i, bool act, 
     }
     const int dn = act ? N : 0;
     const double *pb0 = act ? bu + i : sink + WAVE;
-    double be = (i == N - 1) ? 1.0 : 0.0;
+    double be = (i == N - 1) ? ldexp(1.0, BT_K) : 0.0; // e_{N-1} at the rows' scale
     double *pw = act ? wu + (size_t)(T - 1) * N + i : sink;
     double *ps = (i == 0) ? sbu + (T - 1) : sink;
     const int ds = (i == 0) ? 1 : 0;
-    *pw = be;  // row T-1 holds beta~_{T-1} itself
+    *pw = be;  // row T-1 holds beta~_{T-1} itself (no W behind the last frame)
     *ps = 1.0;
     pw -= dn; ps -= ds;
     auto step = [&](double bnext) {
@@ -63,12 +75,13 @@ __device__ __forceinline__ void backward_own_run(int N, int T, int i, bool act, 
             for (int j = 0; j < L; j++)
                 if (j < N) v += arow[BANDED ? 0 : j] * __shfl(w, j, L);
         }
+        // the row's scale: an exact power of two that puts its sum at 2^BT_K (three instructions
+        // on the chain: exponent, subtract, ldexp; nothing is rounded).  s = 0: nothing can
+        // follow, beta~ = 0 from here on like beta^; s = inf / NaN: the combine pass sees it
         const double s = group_sum<L>(v);
-        const double r0 = __builtin_amdgcn_rcp(s);
-        double r = fma(r0, fma(-s, r0, 1.0), r0);
-        r = s > 0.0 ? r : 0.0; // nothing can follow (or NaN): beta~ = 0 from here on, like beta^
-        be = v * r;
-        *ps = r;
+        const int e = BT_K - __builtin_amdgcn_frexp_exp(s);
+        be = ldexp(v, e);
+        *ps = ldexp(1.0, e);
         pw -= dn; ps -= ds;
     };
     // b of frame T-1, T-2, ... (frame t+1 for t = T-2 .. 0) through a descending cursor, PFF
@@ -136,11 +149,23 @@ k_scan_pair(int N, int U, int only, const double *__restrict__ A, const double *
         backward_own_run<L, false>(N, T, i, act, A, b + f0 * N, wrow + f0 * N, sb + f0, snk);
 }
 
+// a * b * c * d where the product is a normal number although a partial product may leave the
+// range or turn subnormal (beta^ = beta~ * (1/D) * c * kappa, asked for by ghmm_fetch only)
+__device__ inline double mul4_ranged(double a, double b, double c, double d)
+{
+    const double m = (__builtin_amdgcn_frexp_mant(a) * __builtin_amdgcn_frexp_mant(b)) *
+                     (__builtin_amdgcn_frexp_mant(c) * __builtin_amdgcn_frexp_mant(d));
+    const int e = (__builtin_amdgcn_frexp_exp(a) + __builtin_amdgcn_frexp_exp(b)) +
+                  (__builtin_amdgcn_frexp_exp(c) + __builtin_amdgcn_frexp_exp(d));
+    return ldexp(m, e); // (0, inf and NaN: the mantissa is the value itself, its exponent 0)
+}
+
 // gamma, the xi / den sums (one partial slot per (utterance, chunk)) and optionally beta^ from
-// alpha^, c, W and 1/s.  Group = (utterance, chunk of its frames), frames descending.
-// MD = widest band offset that can carry statistics (delta <= MD)
+// alpha^, c, W and the rows' scales.  Group = (utterance, chunk of its frames), frames descending.
+// MD = widest band offset that can carry statistics (delta <= MD).  Returns whether the
+// utterance has to be taken again in the reference's order (see RANGE above).
 template <int L, bool BANDED, bool WANT_BETA, int MD = MAX_DELTA>
-__device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool act, int slot, int tlo, int thi,
+__device__ __forceinline__ bool combine_run(int N, int T, int delta, int i, bool act, int slot, int tlo, int thi,
                                    const double *__restrict__ A, const double *__restrict__ au,
                                    const double *__restrict__ su, const double *__restrict__ wu,
                                    const double *__restrict__ sbu, double *__restrict__ beu,
@@ -178,29 +203,24 @@ __device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool
         }
         return t == T - 1 ? w : v * sbu[t];
     };
-    // kappa / D, 0 when the utterance has no path into the last state (everything is 0 then)
-    auto factor = [&](double D) {
+    // 1 / D (0 where D has left the numbers: the frame is then reported, see `dead`)
+    auto recipD = [&](double D) {
         const double r0 = __builtin_amdgcn_rcp(D);
         double r = fma(r0, fma(-D, r0, 1.0), r0);
         r = fma(r, fma(-D, r, 1.0), r);
-        return (D > 0.0 && D < INFINITY) ? kappa * r : 0.0;
+        return (D > 0.0 && D < INFINITY) ? r : 0.0;
     };
-    // rho of the frame behind the chunk, for the chunk's first xi
-    double facn = 0.0, cn = 0.0, rhon = 0.0;
+    // 1/D of the frame behind the chunk, for the chunk's first xi
+    double rDn = 0.0, cn = 0.0;
     if (thi < T) {
         double wd;
         const double bt = beta_own(thi, pw0[(size_t)thi * dn], wd);
-        const double D = group_sum<L>(pa0[(size_t)thi * dn] * bt);
-        facn = factor(D);
+        rDn = recipD(group_sum<L>(pa0[(size_t)thi * dn] * bt));
         cn = su[thi];
     }
-    if (WANT_BETA && !(kappa > 0.0)) {
-        // no path into the last state: rho from its own recursion, rho_t = c_t s_t rho_{t+1}
-        rhon = su[T - 1];
-        // (c_t s_t first: c_t rho_{t+1} alone can be beyond the largest double where rho_t is not)
-        for (int t = T - 2; t >= thi; t--) rhon = sbu[t] > 0.0 ? rhon * (su[t] / sbu[t]) : 0.0;
-    }
     double dena = 0.0, denc = 0.0;
+    double rhomax = 0.0; // max over the chunk's frames of c_t / D_t = rho_t / kappa
+    bool dead = false;   // a frame whose D_t is 0, inf or NaN
     double *pg = act ? gu + (size_t)(thi - 1) * N + i : sink;
     double *pbe = act ? beu + (size_t)(thi - 1) * N + i : sink;
     auto frame = [&](int t, double w, double al, double ct, double sbt) {
@@ -214,38 +234,38 @@ __device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool
             for (int j = 0; j < L; j++)
                 if (j < N) v += arow[BANDED ? 0 : j] * __shfl(w, j, L);
         }
-        const double bt = t == T - 1 ? w : v * sbt;
+        const double bt = t == T - 1 ? w : v * sbt; // (sbt is a power of two: the scan's beta~ bit for bit)
         const double p = al * bt;
         const double D = group_sum<L>(p);
-        const double fac = factor(D);
-        const double g = p * fac;
+        const double rD = recipD(D);
+        // the frame's share first (<= 1), kappa last: neither product can leave the range
+        // unless gamma itself does
+        const double g = (p * rD) * kappa;
         *pg = g;
         denc += g;
         const double inner = t < T - 1 ? 1.0 : 0.0; // the last frame has no transition behind it
         dena = fma(g, inner, dena);
-        const double rho1 = cn * facn * inner; // rho_{t+1}
-        xi[0] = fma(al * w, rho1, xi[0]);
-        xi[1] = fma(al * wd, rho1, xi[1]);
+        const double rc1 = (cn * rDn) * inner; // c_{t+1} / D_{t+1} = rho_{t+1} / kappa
+        xi[0] = fma(al * w, rc1, xi[0]);
+        xi[1] = fma(al * wd, rc1, xi[1]);
 #pragma unroll
         for (int o = 2; o <= MD; o++)
             if (o <= delta) {
                 const double wj = __shfl_down(w, o, L);
-                xi[o] += (i + o < N) ? al * wj * rho1 : 0.0;
+                xi[o] += (i + o < N) ? al * wj * rc1 : 0.0;
             }
+        const double crd = ct * rD;
+        rhomax = fmax(rhomax, crd);
+        dead |= rD == 0.0;
         if (WANT_BETA) {
-            if (kappa > 0.0) {
-                *pbe = bt * (ct * fac);
-            } else {
-                if (t < T - 1) rhon = sbt > 0.0 ? rhon * (ct / sbt) : 0.0;
-                *pbe = bt > 0.0 ? bt * rhon : 0.0; // (a zero stays zero when rho has overflowed)
-            }
+            *pbe = mul4_ranged(bt, rD, ct, kappa);
             pbe -= dn;
         }
-        facn = fac;
+        rDn = rD;
         cn = ct;
         pg -= dn;
     };
-    // operands of frame t: W_t(i), alpha^_t(i), c_t, 1/s_t, read CB_PF frames ahead with
+    // operands of frame t: W_t(i), alpha^_t(i), c_t, 2^(e_t), read CB_PF frames ahead with
     // addresses clamped into the chunk (never predicated)
     auto cl = [&](int t) { return (size_t)(t < tlo ? tlo : t); };
     double qw[CB_PF], qa[CB_PF], qc[CB_PF], qs[CB_PF];
@@ -275,10 +295,15 @@ __device__ __forceinline__ void combine_run(int N, int T, int delta, int i, bool
     if (act) {
 #pragma unroll
         for (int o = 0; o <= MD; o++) // compile-time indices: the arrays stay in registers
-            if (o <= delta) part_xi[pxi_at(slot, i, o, S)] = aband[o] * xi[o];
+            if (o <= delta) part_xi[pxi_at(slot, i, o, S)] = (aband[o] * xi[o]) * kappa;
         part_dena[pden_at(slot, i, S)] = dena;
         part_denc[pden_at(slot, i, S)] = denc;
     }
+    // the reference's order of operations decides when: there is no path into the last state
+    // (kappa is 0 or NaN), a frame's D left the numbers, or rho_t = kappa c_t / D_t reaches the
+    // rows' scale 2^BT_K (rho'_t = rho_t 2^-BT_K >= 1: the reference's beta^ sees further down)
+    // (every term is uniform over the group's lanes: D_t comes from group_sum)
+    return !(kappa > 0.0) || dead || !(kappa * rhomax < 1.0);
 }
 
 // DENSE = false: A is known (on the host, ghmm_model_set) to be band-diagonal with a_ij = 0
@@ -292,7 +317,8 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
           double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
           double *__restrict__ part_denc, double *__restrict__ sink,
           const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
-          const int *__restrict__ order)
+          const int *__restrict__ order, int *__restrict__ fix_mark, int stamp, int *__restrict__ fix_cnt,
+          int *__restrict__ fix_list)
 {
     const int qs = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     const int i = threadIdx.x % L;
@@ -335,14 +361,59 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
             offband |= act && (A[i * N + j] != 0.0 && j != i && j != i + 1);
         banded = !__any(offband);
     }
+    bool again = false;
     if (banded)
-        combine_run<L, true, WANT_BETA, DENSE ? MAX_DELTA : 1>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
+        again = combine_run<L, true, WANT_BETA, DENSE ? MAX_DELTA : 1>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                         wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
                                         part_dena, part_denc, snk, U * CB_CH);
     else if (DENSE)
-        combine_run<L, false, WANT_BETA>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
+        again = combine_run<L, false, WANT_BETA>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                          wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
                                          part_dena, part_denc, snk, U * CB_CH);
+    // the utterance goes on k_backward_fix's list once, whichever of its chunks asks first
+    // (marks carry the pass's stamp: nothing is ever cleared)
+    if (again && i == 0 && atomicExch(&fix_mark[u], stamp) != stamp) fix_list[atomicAdd(fix_cnt, 1)] = u;
+}
+
+// The utterances k_combine listed, whole, in the reference's own order of operations:
+// calc_beta scaled by the forward pass's c_t with the dense inner loop of TF:1493-1510 (an
+// a_ij = 0 next to an overflowed beta^ makes the reference's NaN; the band-only update would
+// not), gamma = alpha^ beta^ / c_t (TF:1655-1660), xi and den sums on the chain (TF:1601-1618).
+// Their gamma (and beta^) rows and their partial-sum slots are rewritten: chunk slot 0 takes the
+// utterance's sums, the other CB_CH - 1 slots 0.  Launched behind every k_combine (and behind
+// k_backward, for utterances whose band-only update met an overflowed beta^); leaves at once when
+// the list is empty.
+template <int L>
+__global__ void __launch_bounds__(WAVE)
+k_backward_fix(int N, int U, int delta, const double *__restrict__ A, const double *__restrict__ b,
+               const long long *__restrict__ off, const double *__restrict__ alpha,
+               const double *__restrict__ scale, double *__restrict__ beta, double *__restrict__ gamma,
+               double *__restrict__ part_xi, double *__restrict__ part_dena, double *__restrict__ part_denc,
+               double *__restrict__ sink, const int *__restrict__ fix_cnt, const int *__restrict__ fix_list,
+               int *__restrict__ fix_cnt_next, int spu, const double *__restrict__ sinv)
+{   // spu = partial-sum slots per utterance: CB_CH behind k_combine, 1 behind k_backward
+    const int n = *fix_cnt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt_next = 0; // the counter of the next pass
+    if (n == 0) return;
+    const int i = threadIdx.x % L;
+    const bool act = i < N;
+    const int S = U * spu;
+    double *snk = wave_sink(sink);
+    for (int idx = blockIdx.x * (WAVE / L) + threadIdx.x / L; idx < n; idx += gridDim.x * (WAVE / L)) {
+        const int u = fix_list[idx];
+        const long long f0 = off[u];
+        const int T = (int)(off[u + 1] - f0);
+        if (T <= 0) continue; // (never listed)
+        backward_run<L, false>(N, T, delta, i, act, u * spu, A, b + f0 * N, alpha + f0 * N, scale + f0,
+                               sinv ? sinv + f0 : (const double *)nullptr, beta + f0 * N, gamma + f0 * N,
+                               part_xi, part_dena, part_denc, snk, S);
+        if (act)
+            for (int k = 1; k < spu; k++) {
+                for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(u * spu + k, i, o, S)] = 0.0;
+                part_dena[pden_at(u * spu + k, i, S)] = 0.0;
+                part_denc[pden_at(u * spu + k, i, S)] = 0.0;
+            }
+    }
 }
 
 } // namespace ghmm
