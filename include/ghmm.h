@@ -94,7 +94,14 @@ enum {
      * pass of the default tier took again in the reference's own order of operations — no path
      * into the last state, or forward and backward mass more than 200 decades apart at some
      * frame (ghmm_pair.hpp, RANGE).  0 on data the model fits. */
-    GHMM_OPT_REFORDER_COUNT = 7
+    GHMM_OPT_REFORDER_COUNT = 7,
+    /* matrix-core tier, Gaussians too ill-conditioned for the expanded sums although their
+     * variances are not at the floor ("class 2"): 0 (default) their direct-form sums come from
+     * the vector-ALU statistics kernel, launched while the host has recently seen such a
+     * Gaussian, and from an exact recomputation inside the reduction otherwise; 1 always
+     * launch that kernel; 2 never (always the recomputation).  All three are exact; a
+     * measurement / test switch. */
+    GHMM_OPT_VEC_STATS = 8
 };
 int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value);
 int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value);

@@ -53,7 +53,7 @@ struct ghmm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int cus = 256, dev_cus = 256; // grid sizing (GHMM_OPT_CUS) / the device's count
-    int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0;
+    int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0, vec_stats = 0;
     // workspace (grown on demand, never shrunk)
     size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
            cap_lognorm = 0, cap_loglik = 0, cap_pxi = 0, cap_pdena = 0, cap_pdenc = 0, cap_pmu = 0,
@@ -128,6 +128,14 @@ struct ghmm_model {
     int *tshift = nullptr, *sflag = nullptr, *tnext = nullptr; // tnext: the choice for the next preparation
     int *scls = nullptr;  // [NT*16] how each padded Gaussian's statistics are taken (stats_class)
     int *tfull = nullptr; // [NT] the tile's slots are 16 consecutive real Gaussians, even start, G even
+    // sflag's value as the HOST sees it, some launches late (pinned, mapped memory that the
+    // preparing kernels write directly): the last preparation that found a class-2 Gaussian.
+    // run_accumulate launches the vector-ALU k_mixstats only while that is recent (or the model
+    // has just been set from the host); whenever the launch is left out and a class-2 Gaussian
+    // is there after all, k_reduce_all recomputes it exactly itself — the flag only ever chooses
+    // between two exact paths, so a stale value costs time, never correctness.
+    int *hflag_host = nullptr, *hflag_dev = nullptr;
+    int vec_until = 0; // epoch up to which k_mixstats is launched unconditionally (after ghmm_model_set)
     bool banded = false; // A as last set from the host has a_ij = 0 unless j = i or i + 1
     int epoch = 0; // preparation count; anyflag[0] == epoch: this model holds an ill-conditioned Gaussian
     int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
@@ -393,6 +401,10 @@ extern "C" int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value)
         ARG_CHECK(value >= 0 && value <= 65535, "partials out of range");
         ctx->partials = value;
         break;
+    case GHMM_OPT_VEC_STATS:
+        ARG_CHECK(value >= 0 && value <= 2, "vec_stats must be 0, 1 or 2");
+        ctx->vec_stats = value;
+        break;
     case GHMM_OPT_CUS:
         ARG_CHECK(value >= 0 && value <= ctx->dev_cus, "compute units out of range");
         ctx->cus = value ? (int)value : ctx->dev_cus;
@@ -414,6 +426,7 @@ extern "C" int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value)
     case GHMM_OPT_TIMING: *value = ctx->timing; break;
     case GHMM_OPT_PARTIALS: *value = ctx->partials; break;
     case GHMM_OPT_CUS: *value = ctx->cus; break;
+    case GHMM_OPT_VEC_STATS: *value = ctx->vec_stats; break;
     case GHMM_OPT_REFORDER_COUNT: {
         int n = 0, rc = use(ctx);
         if (rc) return rc;
@@ -467,6 +480,10 @@ extern "C" int ghmm_ctx_kernel_time_reset(ghmm_ctx *ctx)
 
 // ------------------------------------------------------------------- model
 
+// preparations for which the vector-ALU statistics kernel stays launched after the host has
+// last seen (or could not yet have seen) a class-2 Gaussian
+constexpr int VEC_WINDOW = 4;
+
 static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
 {
     // pow(2*pi, D/2): the reference's aux1 (TF:1821-1823), evaluated by the host libm
@@ -492,7 +509,7 @@ static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
                            ctx->stream, m->N, m->M, m->D, m->Mp, m->NT, m->DP, m->mean, m->inv_var,
                            m->wk, m->logwk, m->otile, m->tnext, m->oglob, m->Wm, m->wkp, m->logwkp,
                            m->gmap, m->condt, m->condg, m->anyflag, m->sflag, m->epoch, m->dtile,
-                           m->tshift, m->scls);
+                           m->tshift, m->scls, m->hflag_dev);
     }
     return launch_ok("k_prepare_mfma");
 }
@@ -557,6 +574,20 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
                 ghmm_model_destroy(ctx, m);
                 return rc;
             }
+            // the host's late view of sflag (see ghmm_model): 64 bytes of pinned, mapped memory
+            {
+                void *hp = nullptr, *dp = nullptr;
+                if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess ||
+                    hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+                    if (hp) (void)hipHostFree(hp);
+                    ghmm_set_error("ghmm_model_create: no pinned host memory for the statistics flag");
+                    ghmm_model_destroy(ctx, m);
+                    return GHMM_ERR_ALLOC;
+                }
+                m->hflag_host = (int *)hp;
+                m->hflag_dev = (int *)dp;
+                m->hflag_host[0] = -(1 << 30); // no preparation has found a class-2 Gaussian
+            }
             // on the context's stream, like every consumer of these buffers
             hipError_t e = hipMemsetAsync(m->dtile, 0, (size_t)m->NT * m->DP * 8, ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(m->otile, 0, (size_t)m->NT * m->DP * 8, ctx->stream);
@@ -605,6 +636,7 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
                     m->logwkp, m->otile, m->dtile, m->condt, m->tshift, m->sflag, m->tnext, m->tfull, m->scls};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
+    if (m->hflag_host) (void)hipHostFree(m->hflag_host);
     delete m;
 }
 
@@ -628,6 +660,9 @@ extern "C" int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, con
     // pageable host memory: the copies above have consumed the buffers on return
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     m->epoch++; // a new set of parameters
+    // the host cannot know yet what this model's statistics classes are: k_mixstats is launched
+    // (and leaves at once where it has nothing to do) for the first preparations behind this one
+    m->vec_until = m->epoch + VEC_WINDOW;
     return model_prepare(ctx, m, true);
 }
 
@@ -1346,7 +1381,18 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         }
         if (rc || (rc = launch_ok("k_mixstats_mfma"))) return rc;
     }
-    if (P > 0) {
+    // matrix-core tier: the vector-ALU kernel has work only when the model holds class-2
+    // Gaussians (ghmm_mfma.hpp stats_class), which the host learns some launches late from
+    // pinned memory (hflag_host).  Launched while that was recently the case or the model has
+    // just come from the host; otherwise left out (4.5 us of an idle 1 000-block launch per
+    // iteration), and k_reduce_all recomputes a class-2 Gaussian exactly should one be there.
+    bool vec = P > 0;
+    if (vec && mfma && G <= MS_MAXG) {
+        const int seen = *(volatile int *)m->hflag_host;
+        vec = m->epoch <= m->vec_until || (m->epoch - seen) <= VEC_WINDOW;
+        if (ctx->vec_stats) vec = ctx->vec_stats == 1;
+    }
+    if (vec) {
         // vector-ALU statistics: the whole job on that tier, or (matrix-core tier) only
         // when the model holds ill-conditioned Gaussians, whose sums it then supplies
         kscope ks(ctx, GHMM_K_MIXSTATS);
@@ -1362,7 +1408,8 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         ra.S = ctx->slots;
         ra.lpart = ctx->loglik_pieces ? ctx->lpart : nullptr;
         ra.logk = ctx->logk;
-        ra.P1 = (int)P; ra.part_mu = ctx->part_mu; ra.part_var = ctx->part_var;
+        ra.P1 = vec ? (int)P : 0; ra.part_mu = ctx->part_mu; ra.part_var = ctx->part_var;
+        ra.vec = vec ? 1 : 0;
         ra.Pm = (mfma && c->F > 0) ? Pm : 0;
         ra.NT = m->NT; ra.DP = m->DP; ra.ES = m->NE * 16;
         ra.part_m = ctx->part_m; ra.condg = m->condg; ra.oglob = m->oglob; ra.mean = m->mean;
@@ -1501,7 +1548,7 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
                                pow(2.0 * M_PI, m->D / 2.0), m->A, m->c, m->mean, m->inv_var, m->det, m->wk,
                                m->logwk, m->logA, lds_doubles, m->Mp, m->NT, m->DP, m->oglob, m->Wm, m->wkp,
                                m->logwkp, m->gmap, m->condg, m->anyflag, m->epoch, m->otile, m->tnext,
-                               m->condt, m->dtile, m->tshift, m->sflag, (int)ctx->delta, m->scls);
+                               m->condt, m->dtile, m->tshift, m->sflag, (int)ctx->delta, m->scls, m->hflag_dev);
             return launch_ok("k_mstep_mfma");
         }
         hipLaunchKernelGGL(k_mstep, dim3((unsigned)m->N), dim3(MS2_THREADS), (size_t)lds_doubles * 8,

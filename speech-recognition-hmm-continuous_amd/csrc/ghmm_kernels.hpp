@@ -897,8 +897,9 @@ __device__ inline double block_sum_fixed(double v, double *sh)
 struct reduce_args {
     int N, M, D, U, delta;
     int S; // slots of the utterance partials: one per utterance, or one per (utterance, chunk)
-    // vector-ALU partials
-    int P1;
+    // vector-ALU partials (vec == 0: k_mixstats was not launched; a class-2 Gaussian is then
+    // recomputed here, exactly)
+    int P1, vec;
     const double *part_mu, *part_var;
     // matrix-core partials (Pm == 0: tier not in use)
     int Pm, NT, DP, ES;
@@ -939,23 +940,83 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         constexpr int SL = RD_THREADS / 128;
         const int e = tid & 127, half = tid >> 7;
         const int cls = a.Pm > 0 ? a.scls[gp] : 2;
-        if (cls != 2) {
-            // four independent chains (fixed assignment of partials to chains: reproducible),
-            // so that the loads of a thread overlap
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        // The reference's direct form over every frame that carries weight, by this block alone
+        // (rare, ~0.1 ms).  Lane = frame for the weights (64 frames per wave step, waves
+        // interleaved), then lane = coefficient for every such frame; fixed order throughout.
+        auto recompute_exact = [&]() {
+            const int st = g / M, w = tid >> 6, l = tid & 63, NW = RD_THREADS / 64;
+            for (int d0 = 0; d0 < D; d0 += 64) { // (coefficient counts beyond 64: 64 at a time)
+                const int d = d0 + l;
+                const double mu = d < D ? a.mean[(size_t)g * D + d] : 0.0;
+                double am = 0.0, av = 0.0, ac = 0.0;
+                for (long long t0 = (long long)w * 64; t0 < a.F; t0 += (long long)NW * 64) {
+                    const long long t = t0 + l;
+                    const double wt = t < a.F ? a.gamma[t * N + st] * a.post[t * G + g] : 0.0;
+                    unsigned long long m = __ballot(wt != 0.0);
+                    while (m) {
+                        const int k = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const double wk = __shfl(wt, k, 64);
+                        const double x = d < D ? a.X[(t0 + k) * D + d] : 0.0;
+                        const double dif = x - mu;
+                        am += wk * x;
+                        av += wk * (dif * dif);
+                        ac += wk;
+                    }
+                }
+                // waves in order: sh[w*64 + l] (mean sums), sh2 (variance sums); the count from lane 0
+                __syncthreads();
+                sh[tid] = am;
+                sh2[tid] = av;
+                __syncthreads();
+                if (tid < 64) {
+                    double sm = 0.0, sv = 0.0;
+                    for (int q = 0; q < NW; q++) {
+                        sm += sh[q * 64 + tid];
+                        sv += sh2[q * 64 + tid];
+                    }
+                    if (d0 + tid < D) {
+                        num_mu[(size_t)g * D + d0 + tid] = sm;
+                        num_var[(size_t)g * D + d0 + tid] = sv;
+                    }
+                }
+                __syncthreads();
+                sh[tid] = ac;
+                __syncthreads();
+                if (tid == 0 && d0 == 0) {
+                    double sc = 0.0;
+                    for (int q = 0; q < NW; q++) sc += sh[q * 64];
+                    num_c[g] = sc;
+                }
+            }
+        };
+        if (cls == 2 && !a.vec) {
+            // k_mixstats was not launched (the host had not seen this preparation's class-2
+            // Gaussian yet, ghmm_hip.hip run_accumulate): taken here, exactly
+            recompute_exact();
+        } else if (cls != 2) {
+            // sixteen independent chains (fixed assignment of partials to chains: reproducible),
+            // so that the loads of a thread overlap: 32 partials per thread are two rounds of
+            // loads in flight, not eight
+            constexpr int CH = 16;
+            double vch[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) vch[k] = 0.0;
             if (e < a.ES) {
                 const size_t pst = (size_t)a.NT * 16 * a.ES;
                 const double *pm = a.part_m + (size_t)gp * a.ES + e;
                 int p = half;
-                for (; p + 3 * SL < a.Pm; p += 4 * SL) {
-                    v0 += pm[(size_t)p * pst];
-                    v1 += pm[(size_t)(p + SL) * pst];
-                    v2 += pm[(size_t)(p + 2 * SL) * pst];
-                    v3 += pm[(size_t)(p + 3 * SL) * pst];
+                for (; p + (CH - 1) * SL < a.Pm; p += CH * SL) {
+#pragma unroll
+                    for (int k = 0; k < CH; k++) vch[k] += pm[(size_t)(p + k * SL) * pst];
                 }
-                for (; p < a.Pm; p += SL) v0 += pm[(size_t)p * pst];
+                for (; p < a.Pm; p += SL) vch[0] += pm[(size_t)p * pst];
             }
-            sh[tid] = (v0 + v1) + (v2 + v3);
+#pragma unroll
+            for (int k = CH / 2; k > 0; k >>= 1)
+#pragma unroll
+                for (int q = 0; q < k; q++) vch[q] += vch[q + k];
+            sh[tid] = vch[0];
             __syncthreads();
             if (tid < 128) {
                 double t = sh[tid];
@@ -984,54 +1045,8 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
                     }
                 }
             }
-            if (cls == 1 && __syncthreads_or(bad ? 1 : 0)) {
-                // A collapsed component whose variance statistic has come up to the floor: the
-                // reference's direct form over every frame, by this block alone (rare, ~0.1 ms).
-                // Lane = frame for the weights (64 frames per wave step, waves interleaved), then
-                // lane = coefficient for every frame that carries weight; fixed order throughout.
-                const int st = g / M, w = tid >> 6, l = tid & 63, NW = RD_THREADS / 64;
-                const double mu = l < D ? a.mean[(size_t)g * D + l] : 0.0;
-                double am = 0.0, av = 0.0, ac = 0.0;
-                for (long long t0 = (long long)w * 64; t0 < a.F; t0 += (long long)NW * 64) {
-                    const long long t = t0 + l;
-                    const double wt = t < a.F ? a.gamma[t * N + st] * a.post[t * G + g] : 0.0;
-                    unsigned long long m = __ballot(wt != 0.0);
-                    while (m) {
-                        const int k = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        const double wk = __shfl(wt, k, 64);
-                        const double x = l < D ? a.X[(t0 + k) * D + l] : 0.0;
-                        const double dif = x - mu;
-                        am += wk * x;
-                        av += wk * (dif * dif);
-                        ac += wk;
-                    }
-                }
-                // waves in order: sh[w*64 + l] (mean sums), sh2 (variance sums); the count from lane 0
-                __syncthreads();
-                sh[tid] = am;
-                sh2[tid] = av;
-                __syncthreads();
-                if (tid < 64) {
-                    double sm = 0.0, sv = 0.0;
-                    for (int q = 0; q < NW; q++) {
-                        sm += sh[q * 64 + tid];
-                        sv += sh2[q * 64 + tid];
-                    }
-                    if (tid < D) {
-                        num_mu[(size_t)g * D + tid] = sm;
-                        num_var[(size_t)g * D + tid] = sv;
-                    }
-                }
-                __syncthreads();
-                sh[tid] = ac;
-                __syncthreads();
-                if (tid == 0) {
-                    double sc = 0.0;
-                    for (int q = 0; q < NW; q++) sc += sh[q * 64];
-                    num_c[g] = sc;
-                }
-            }
+            // A collapsed component whose variance statistic has come up to the floor
+            if (cls == 1 && __syncthreads_or(bad ? 1 : 0)) recompute_exact();
         } else {
             const long long E = (long long)G * D1;
             for (int d0 = 0; d0 < D1; d0 += 128) {

@@ -155,7 +155,8 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
                double *__restrict__ Wm, double *__restrict__ wkp, double *__restrict__ logwkp,
                int *__restrict__ gmap, double *__restrict__ condt, double *__restrict__ condg,
                int *__restrict__ anyflag, int *__restrict__ sflag, int epoch,
-               double *__restrict__ dtile, int *__restrict__ tshift, int *__restrict__ scls)
+               double *__restrict__ dtile, int *__restrict__ tshift, int *__restrict__ scls,
+               int *__restrict__ hflag)
 {
     __shared__ double sh0[64], sh1[64], sh2[64];
     const int gp = blockIdx.x, t = threadIdx.x;
@@ -211,7 +212,10 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
         // (flag[0] == the model's preparation count means "flagged now": nothing has to
         // clear it, every writer of one preparation stores the same value)
         if (real && c0 > COND_MAX) anyflag[0] = epoch;
-        if (scls[gp] == 2) sflag[0] = epoch;
+        if (scls[gp] == 2) {
+            sflag[0] = epoch;
+            hflag[0] = epoch; // (host memory: tells the host, some time later, to launch k_mixstats)
+        }
     }
 }
 
@@ -232,7 +236,8 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
              double *__restrict__ logwkp, int *__restrict__ gmap, double *__restrict__ condg,
              int *__restrict__ anyflag, int epoch, const double *__restrict__ otile,
              const int *__restrict__ tnext, double *__restrict__ condt, double *__restrict__ dtile,
-             int *__restrict__ tshift, int *__restrict__ sflag, int delta, int *__restrict__ scls)
+             int *__restrict__ tshift, int *__restrict__ sflag, int delta, int *__restrict__ scls,
+             int *__restrict__ hflag)
 {
     extern __shared__ double vs[]; // [lds_doubles] staging of mstep_state | og[DP] | red[MSF_THREADS]
     double *og = vs + lds_doubles, *red = og + DP;
@@ -318,7 +323,10 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
             const int cls = stats_class(real, cg, wide);
             scls[gp] = cls;
             if (real && c0 > COND_MAX) anyflag[0] = epoch;
-            if (cls == 2) sflag[0] = epoch;
+            if (cls == 2) {
+                sflag[0] = epoch;
+                hflag[0] = epoch; // (host memory, see k_prepare_mfma)
+            }
         }
     }
 }

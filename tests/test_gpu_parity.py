@@ -1085,6 +1085,46 @@ def test_fuzz_harsh_models_against_oracle(G, ctx, seed, wide, subnormal):
         pytest.skip("the reference's own statistics are not finite for this seed")
 
 
+def test_class2_gaussians_both_exact_paths(G, ctx):
+    """Gaussians that the expanded sums cannot carry although their variances are not at the
+    floor (stats_class 2: one coefficient with sigma = 0.01 sitting on a frame its state
+    occupies): their statistics come from the vector-ALU kernel when the host launches it
+    (GHMM_OPT_VEC_STATS 1, and what auto does right after ghmm_model_set) and from the exact
+    recomputation inside k_reduce_all when it does not (2: what auto does when such a Gaussian
+    appears in a model that had none for a few iterations).  Both against the oracle, then EM
+    iterations in auto mode against the oracle's."""
+    hm, X, lens = synth_case(G, 10, 8, 39, [300, 211, 128, 77], perturb=0.05)
+    _, d0 = O.estep(hm, X, lens)
+    occ = d0["alpha"] * d0["beta"] / d0["scale"][:, None]
+    for (i, j, d) in ((4, 3, 7), (0, 0, 38), (9, 7, 0)):
+        f = int(np.argmax(occ[:, i] * d0["post"].reshape(-1, 10, 8)[:, i, j]))
+        old_var = 1.0 / hm.inv_var[i, j, d]
+        hm.mean[i, j, d] = X[f, d]
+        hm.inv_var[i, j, d] = 1.0 / 1e-4
+        hm.det[i, j] *= 1e-4 / old_var
+    ref, _ = O.estep(hm, X, lens, dumps=False)
+    corpus = ctx.corpus(X, lens)
+    stats = ctx.stats(10, 8, 39)
+    try:
+        for mode in (1, 2, 0):
+            ctx.set_option(G.OPT_VEC_STATS, mode)
+            model = ctx.model(hm)
+            ctx.estep(model, corpus, stats)
+            assert_close(stats.download(), ref, what=f"class-2 statistics, GHMM_OPT_VEC_STATS {mode}")
+            if mode == 0:
+                cur = hm
+                for it in range(6):   # past the window in which the kernel is launched unconditionally
+                    ctx.estep(model, corpus, stats)
+                    r, _ = O.estep(cur, X, lens, dumps=False)
+                    assert_close(stats.download(), r, what=f"iteration {it}")
+                    ctx.mstep(model, stats)
+                    cur = O.mstep(cur, r)
+            model.close()
+    finally:
+        ctx.set_option(G.OPT_VEC_STATS, 0)
+        corpus.close(); stats.close()
+
+
 def test_no_utterance_of_a_fitting_model_is_taken_again(G, ctx):
     """On data the model fits (the benchmark's generator, ragged lengths) the gamma / xi pass
     must not hand anything to the reference-order kernel: the counter stays 0."""
