@@ -13,7 +13,7 @@ for spec in "$@"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I"$HERE/include" -Wno-unused-parameter -Wno-pass-failed \
         -munsafe-fp-atomics -ffp-contract=on $flags -c "$PKG/csrc/ghmm_hip.hip" -o "$PKG/build/lab$tag.o" &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$PKG/build/libghmm_lab$tag.so" \
-        "$PKG/build/ghmm_synth.o" "$PKG/build/ghmm_io.o" "$PKG/build/ghmm_init.o" "$PKG/build/lab$tag.o" -lm &&
+        "$PKG/build/ghmm_synth.o" "$PKG/build/ghmm_io.o" "$PKG/build/ghmm_init.o" "$PKG/build/ghmm_rendezvous.o" "$PKG/build/lab$tag.o" -lm &&
     echo "built lab $tag ($flags)"
   ) &
 done

@@ -581,8 +581,86 @@ __device__ const double EXP2_32[32] = {
     0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
     0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
 
-// exp on four values at once (four independent chains): x = n ln2/32 + r, exp(x) =
-// 2^(n>>5) * 2^((n&31)/32) * exp(r).  `etab` = EXP2_32 in LDS.
+// 2^(j/256), j = 0..255, correctly rounded (60-digit decimal arithmetic)
+__device__ const double EXP2_256[256] = {
+    0x1.0000000000000p+0, 0x1.00b1afa5abcbfp+0, 0x1.0163da9fb3335p+0, 0x1.02168143b0281p+0,
+    0x1.02c9a3e778061p+0, 0x1.037d42e11bbccp+0, 0x1.04315e86e7f85p+0, 0x1.04e5f72f654b1p+0,
+    0x1.059b0d3158574p+0, 0x1.0650a0e3c1f89p+0, 0x1.0706b29ddf6dep+0, 0x1.07bd42b72a836p+0,
+    0x1.0874518759bc8p+0, 0x1.092bdf66607e0p+0, 0x1.09e3ecac6f383p+0, 0x1.0a9c79b1f3919p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0c0f145e46c85p+0, 0x1.0cc922b7247f7p+0, 0x1.0d83b23395decp+0,
+    0x1.0e3ec32d3d1a2p+0, 0x1.0efa55fdfa9c5p+0, 0x1.0fb66affed31bp+0, 0x1.1073028d7233ep+0,
+    0x1.11301d0125b51p+0, 0x1.11edbab5e2ab6p+0, 0x1.12abdc06c31ccp+0, 0x1.136a814f204abp+0,
+    0x1.1429aaea92de0p+0, 0x1.14e95934f312ep+0, 0x1.15a98c8a58e51p+0, 0x1.166a45471c3c2p+0,
+    0x1.172b83c7d517bp+0, 0x1.17ed48695bbc0p+0, 0x1.18af9388c8deap+0, 0x1.1972658375d2fp+0,
+    0x1.1a35beb6fcb75p+0, 0x1.1af99f8138a1cp+0, 0x1.1bbe084045cd4p+0, 0x1.1c82f95281c6bp+0,
+    0x1.1d4873168b9aap+0, 0x1.1e0e75eb44027p+0, 0x1.1ed5022fcd91dp+0, 0x1.1f9c18438ce4dp+0,
+    0x1.2063b88628cd6p+0, 0x1.212be3578a819p+0, 0x1.21f49917ddc96p+0, 0x1.22bdda27912d1p+0,
+    0x1.2387a6e756238p+0, 0x1.2451ffb82140ap+0, 0x1.251ce4fb2a63fp+0, 0x1.25e85711ece75p+0,
+    0x1.26b4565e27cddp+0, 0x1.2780e341ddf29p+0, 0x1.284dfe1f56381p+0, 0x1.291ba7591bb70p+0,
+    0x1.29e9df51fdee1p+0, 0x1.2ab8a66d10f13p+0, 0x1.2b87fd0dad990p+0, 0x1.2c57e39771b2fp+0,
+    0x1.2d285a6e4030bp+0, 0x1.2df961f641589p+0, 0x1.2ecafa93e2f56p+0, 0x1.2f9d24abd886bp+0,
+    0x1.306fe0a31b715p+0, 0x1.31432edeeb2fdp+0, 0x1.32170fc4cd831p+0, 0x1.32eb83ba8ea32p+0,
+    0x1.33c08b26416ffp+0, 0x1.3496266e3fa2dp+0, 0x1.356c55f929ff1p+0, 0x1.36431a2de883bp+0,
+    0x1.371a7373aa9cbp+0, 0x1.37f26231e754ap+0, 0x1.38cae6d05d866p+0, 0x1.39a401b7140efp+0,
+    0x1.3a7db34e59ff7p+0, 0x1.3b57fbfec6cf4p+0, 0x1.3c32dc313a8e5p+0, 0x1.3d0e544ede173p+0,
+    0x1.3dea64c123422p+0, 0x1.3ec70df1c5175p+0, 0x1.3fa4504ac801cp+0, 0x1.40822c367a024p+0,
+    0x1.4160a21f72e2ap+0, 0x1.423fb2709468ap+0, 0x1.431f5d950a897p+0, 0x1.43ffa3f84b9d4p+0,
+    0x1.44e086061892dp+0, 0x1.45c2042a7d232p+0, 0x1.46a41ed1d0057p+0, 0x1.4786d668b3237p+0,
+    0x1.486a2b5c13cd0p+0, 0x1.494e1e192aed2p+0, 0x1.4a32af0d7d3dep+0, 0x1.4b17dea6db7d7p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4ce41b817c114p+0, 0x1.4dcb299fddd0dp+0, 0x1.4eb2d81d8abffp+0,
+    0x1.4f9b2769d2ca7p+0, 0x1.508417f4531eep+0, 0x1.516daa2cf6642p+0, 0x1.5257de83f4eefp+0,
+    0x1.5342b569d4f82p+0, 0x1.542e2f4f6ad27p+0, 0x1.551a4ca5d920fp+0, 0x1.56070dde910d2p+0,
+    0x1.56f4736b527dap+0, 0x1.57e27dbe2c4cfp+0, 0x1.58d12d497c7fdp+0, 0x1.59c0827ff07ccp+0,
+    0x1.5ab07dd485429p+0, 0x1.5ba11fba87a03p+0, 0x1.5c9268a5946b7p+0, 0x1.5d84590998b93p+0,
+    0x1.5e76f15ad2148p+0, 0x1.5f6a320dceb71p+0, 0x1.605e1b976dc09p+0, 0x1.6152ae6cdf6f4p+0,
+    0x1.6247eb03a5585p+0, 0x1.633dd1d1929fdp+0, 0x1.6434634ccc320p+0, 0x1.652b9febc8fb7p+0,
+    0x1.6623882552225p+0, 0x1.671c1c70833f6p+0, 0x1.68155d44ca973p+0, 0x1.690f4b19e9538p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6b052fa75173ep+0, 0x1.6c012750bdabfp+0, 0x1.6cfdcddd47645p+0,
+    0x1.6dfb23c651a2fp+0, 0x1.6ef9298593ae5p+0, 0x1.6ff7df9519484p+0, 0x1.70f7466f42e87p+0,
+    0x1.71f75e8ec5f74p+0, 0x1.72f8286ead08ap+0, 0x1.73f9a48a58174p+0, 0x1.74fbd35d7cbfdp+0,
+    0x1.75feb564267c9p+0, 0x1.77024b1ab6e09p+0, 0x1.780694fde5d3fp+0, 0x1.790b938ac1cf6p+0,
+    0x1.7a11473eb0187p+0, 0x1.7b17b0976cfdbp+0, 0x1.7c1ed0130c132p+0, 0x1.7d26a62ff86f0p+0,
+    0x1.7e2f336cf4e62p+0, 0x1.7f3878491c491p+0, 0x1.80427543e1a12p+0, 0x1.814d2add106d9p+0,
+    0x1.82589994cce13p+0, 0x1.8364c1eb941f7p+0, 0x1.8471a4623c7adp+0, 0x1.857f4179f5b21p+0,
+    0x1.868d99b4492edp+0, 0x1.879cad931a436p+0, 0x1.88ac7d98a6699p+0, 0x1.89bd0a478580fp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8be05bad61778p+0, 0x1.8cf3216b5448cp+0, 0x1.8e06a5e0866d9p+0,
+    0x1.8f1ae99157736p+0, 0x1.902fed0282c8ap+0, 0x1.9145b0b91ffc6p+0, 0x1.925c353aa2fe2p+0,
+    0x1.93737b0cdc5e5p+0, 0x1.948b82b5f98e5p+0, 0x1.95a44cbc8520fp+0, 0x1.96bdd9a7670b3p+0,
+    0x1.97d829fde4e50p+0, 0x1.98f33e47a22a2p+0, 0x1.9a0f170ca07bap+0, 0x1.9b2bb4d53fe0dp+0,
+    0x1.9c49182a3f090p+0, 0x1.9d674194bb8d5p+0, 0x1.9e86319e32323p+0, 0x1.9fa5e8d07f29ep+0,
+    0x1.a0c667b5de565p+0, 0x1.a1e7aed8eb8bbp+0, 0x1.a309bec4a2d33p+0, 0x1.a42c980460ad8p+0,
+    0x1.a5503b23e255dp+0, 0x1.a674a8af46052p+0, 0x1.a799e1330b358p+0, 0x1.a8bfe53c12e59p+0,
+    0x1.a9e6b5579fdbfp+0, 0x1.ab0e521356ebap+0, 0x1.ac36bbfd3f37ap+0, 0x1.ad5ff3a3c2774p+0,
+    0x1.ae89f995ad3adp+0, 0x1.afb4ce622f2ffp+0, 0x1.b0e07298db666p+0, 0x1.b20ce6c9a8952p+0,
+    0x1.b33a2b84f15fbp+0, 0x1.b468415b749b1p+0, 0x1.b59728de5593ap+0, 0x1.b6c6e29f1c52ap+0,
+    0x1.b7f76f2fb5e47p+0, 0x1.b928cf22749e4p+0, 0x1.ba5b030a1064ap+0, 0x1.bb8e0b79a6f1fp+0,
+    0x1.bcc1e904bc1d2p+0, 0x1.bdf69c3f3a207p+0, 0x1.bf2c25bd71e09p+0, 0x1.c06286141b33dp+0,
+    0x1.c199bdd85529cp+0, 0x1.c2d1cd9fa652cp+0, 0x1.c40ab5fffd07ap+0, 0x1.c544778fafb22p+0,
+    0x1.c67f12e57d14bp+0, 0x1.c7ba88988c933p+0, 0x1.c8f6d9406e7b5p+0, 0x1.ca3405751c4dbp+0,
+    0x1.cb720dcef9069p+0, 0x1.ccb0f2e6d1675p+0, 0x1.cdf0b555dc3fap+0, 0x1.cf3155b5bab74p+0,
+    0x1.d072d4a07897cp+0, 0x1.d1b532b08c968p+0, 0x1.d2f87080d89f2p+0, 0x1.d43c8eacaa1d6p+0,
+    0x1.d5818dcfba487p+0, 0x1.d6c76e862e6d3p+0, 0x1.d80e316c98398p+0, 0x1.d955d71ff6075p+0,
+    0x1.da9e603db3285p+0, 0x1.dbe7cd63a8315p+0, 0x1.dd321f301b460p+0, 0x1.de7d5641c0658p+0,
+    0x1.dfc97337b9b5fp+0, 0x1.e11676b197d17p+0, 0x1.e264614f5a129p+0, 0x1.e3b333b16ee12p+0,
+    0x1.e502ee78b3ff6p+0, 0x1.e653924676d76p+0, 0x1.e7a51fbc74c83p+0, 0x1.e8f7977cdb740p+0,
+    0x1.ea4afa2a490dap+0, 0x1.eb9f4867cca6ep+0, 0x1.ecf482d8e67f1p+0, 0x1.ee4aaa2188510p+0,
+    0x1.efa1bee615a27p+0, 0x1.f0f9c1cb6412ap+0, 0x1.f252b376bba97p+0, 0x1.f3ac948dd7274p+0,
+    0x1.f50765b6e4540p+0, 0x1.f6632798844f8p+0, 0x1.f7bfdad9cbe14p+0, 0x1.f91d802243c89p+0,
+    0x1.fa7c1819e90d8p+0, 0x1.fbdba3692d514p+0, 0x1.fd3c22b8f71f1p+0, 0x1.fe9d96b2a23d9p+0};
+
+// Table of the emission kernels' exp: 256 entries of 2^(j/256) (the argument reduced to |r| <=
+// ln2/512, a cubic for exp(r) - 1 = r (1 + r/2 + r^2/6 + r^3/24), truncation r^5/120 = 4e-17) or,
+// GHMM_EXP_TAB = 32, round 2's 32 entries with a quintic.  With 32 entries every lane of a
+// ds_read_b64 group reads its own bank pair (or a broadcast); 256 entries conflict ~3-way on four
+// reads per tile and save two of twelve f64 instructions per value — the f64 pipe, which MFMA and
+// vector instructions share without overlap, is what the kernel is bound by.
+#ifndef GHMM_EXP_TAB
+#define GHMM_EXP_TAB 256
+#endif
+constexpr int EXP_TAB = GHMM_EXP_TAB;
+
+// exp on four values at once (four independent chains): x = n ln2/EXP_TAB + r, exp(x) =
+// 2^(n / EXP_TAB) * 2^((n % EXP_TAB)/EXP_TAB) * exp(r).  `etab` = the table in LDS.
 __device__ inline void exp_emis4(const v4d &x, const double *__restrict__ etab, double (&out)[4])
 {
     double r[4], p[4];
@@ -598,25 +676,34 @@ __device__ inline void exp_emis4(const v4d &x, const double *__restrict__ etab, 
         const unsigned hi = (unsigned)__double2hiint(x[q]);
         const double xc = __hiloint2double((int)(hi < 0xC0877000u ? hi : 0xC0877000u), __double2loint(x[q]));
         // round to nearest by adding 1.5 * 2^52: the integer lands in the low mantissa bits
-        const double t = fma(xc, 0x1.71547652b82fep+5, 0x1.8p52); // 32 / ln2
-        ki[q] = __double2loint(t);
-        const double k = t - 0x1.8p52;
-        r[q] = fma(-k, 0x1.62e42fee00000p-6, xc);  // ln2/32, high part (k * hi is exact)
-        r[q] = fma(-k, 0x1.a39ef35793c76p-38, r[q]);
-        p[q] = 1.38888888888888888889e-03; // 1/720
+        if (EXP_TAB == 256) {
+            const double t = fma(xc, 0x1.71547652b82fep+8, 0x1.8p52); // 256 / ln2
+            ki[q] = __double2loint(t);
+            const double k = t - 0x1.8p52;
+            r[q] = fma(-k, 0x1.62e42fe000000p-9, xc);  // ln2/256, high part (k * hi is exact)
+            r[q] = fma(-k, 0x1.f473de6af278fp-38, r[q]);
+            p[q] = 4.16666666666666666667e-02; // 1/24
+        } else {
+            const double t = fma(xc, 0x1.71547652b82fep+5, 0x1.8p52); // 32 / ln2
+            ki[q] = __double2loint(t);
+            const double k = t - 0x1.8p52;
+            r[q] = fma(-k, 0x1.62e42fee00000p-6, xc);  // ln2/32, high part (k * hi is exact)
+            r[q] = fma(-k, 0x1.a39ef35793c76p-38, r[q]);
+            p[q] = 1.38888888888888888889e-03; // 1/720
+        }
     }
     const double cf[5] = {8.33333333333333333333e-03, 4.16666666666666666667e-02,
                           1.66666666666666666667e-01, 0.5, 1.0};
 #pragma unroll
-    for (int t = 0; t < 5; t++)
+    for (int t = (EXP_TAB == 256 ? 2 : 0); t < 5; t++)
 #pragma unroll
         for (int q = 0; q < 4; q++) p[q] = fma(p[q], r[q], cf[t]);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         // (the table is read here, not ahead of the polynomial: four waves per SIMD cover the
         // LDS latency, and the kernel sits at its 128-register limit)
-        const double tj = etab[ki[q] & 31];
-        out[q] = ldexp(fma(tj, p[q] * r[q], tj), ki[q] >> 5);
+        const double tj = etab[ki[q] & (EXP_TAB - 1)];
+        out[q] = ldexp(fma(tj, p[q] * r[q], tj), ki[q] >> (EXP_TAB == 256 ? 8 : 5));
     }
 }
 
@@ -705,7 +792,7 @@ __host__ __device__ inline size_t ems_lds_bytes(int TC, int DP, int waves, int M
 {
     const int KS = DP / 2, XS = DP + 2;
     return (size_t)TC * KS * 64 * 8 + (ems_direct(MP, OUT) ? 0 : (size_t)waves * 16 * XS * 8) + (size_t)DP * 8 + // (see the kernel)
-           (size_t)TC * 16 * 8 + (size_t)TC * DP * 8 + 32 * 8 + (size_t)TC * 16 * 4 + (size_t)TC * 4 * 2 + 64;
+           (size_t)TC * 16 * 8 + (size_t)TC * DP * 8 + EXP_TAB * 8 + (size_t)TC * 16 * 4 + (size_t)TC * 4 * 2 + 64;
 }
 
 // OUT 0: b (recogniser, RF:860-889); 1: b and posteriors (trainer, TF:1749-1783);
@@ -740,8 +827,8 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
     // tiles that hold a variance-floored component take that component's mean as their offset:
     // dl = offset - oglob (subtracted from the x operand of that tile), tsl = "shifted"
     double *dl = wkl + (size_t)TC * 16;              // [TC][DP]
-    double *etab = dl + (size_t)TC * DP;             // [32]
-    int *gml = (int *)(etab + 32);                   // [TC][16] real Gaussian of a slot, -1 = padding
+    double *etab = dl + (size_t)TC * DP;             // [EXP_TAB]
+    int *gml = (int *)(etab + EXP_TAB);                   // [TC][16] real Gaussian of a slot, -1 = padding
     int *tsl = gml + (size_t)TC * 16;                // [TC]
     int *tfl = tsl + TC;                             // [TC] all 16 slots real, consecutive, even start
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
@@ -850,7 +937,7 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
         if (tid < DP) ol[tid] = tid < D ? ol_v : 0.0;
         if (tid < nd) dl[tid] = dl_v;
     }
-    if (tid < 32) etab[tid] = EXP2_32[tid];
+    if (tid < EXP_TAB) etab[tid] = EXP_TAB == 256 ? EXP2_256[tid] : EXP2_32[tid & 31];
     __syncthreads();
     // per-tile flags of the chunk as bit masks in scalar registers (TC <= 32): no LDS round trip
     // per tile for them
@@ -1093,9 +1180,11 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                 double t = 0.0;
 #pragma unroll
                 for (int tt = 0; tt < TPS; tt++) {
-                    if (GS == 4) t += (e[tt][0] + e[tt][1]) + (e[tt][2] + e[tt][3]);
-                    else if (GS == 2) t += e[tt][2 * v] + e[tt][2 * v + 1];
-                    else t += e[tt][v];
+                    double ts;
+                    if (GS == 4) ts = (e[tt][0] + e[tt][1]) + (e[tt][2] + e[tt][3]);
+                    else if (GS == 2) ts = e[tt][2 * v] + e[tt][2 * v + 1];
+                    else ts = e[tt][v];
+                    t = tt == 0 ? ts : t + ts; // (no 0 + x: hipcc keeps that addition, it canonicalises)
                 }
                 sm[v] = (GHMM_LAB & 8) ? e[0][v] : kq_sum<MPL>(t);
             }
