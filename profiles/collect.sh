@@ -3,7 +3,7 @@
 #   kernel-trace statistics of the bench workload, the four PMC passes, and kernel-trace
 #   statistics of the decode, 64-mixture and 2 000-state side workloads.
 # usage: profiles/collect.sh <tag>
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -16,7 +16,9 @@ stats() { # $1 = name, rest = command after --
 stats bench python3 bench.py --no-extras --no-cpu-baseline --steps 40 --warmup 3
 echo "bench stats done"
 bash profiles/pmc_passes.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1
-python3 profiles/pmc_summary.py "$OUT/pmc" k_emission_sched k_mixstats_mfma k_scan_pair k_combine k_reduce_all k_mstep_mfma > "$OUT/pmc_summary.txt"
+python3 profiles/pmc_summary.py "$OUT/pmc" k_emission_sched k_mixstats_mfma k_scan_pair k_combine k_backward_fix k_reduce_all k_mstep_mfma > "$OUT/pmc_summary.txt"
+cp profiles/emission_traffic.json "$OUT/emission_traffic_before.json"
+python3 profiles/emission_traffic.py "$OUT/pmc" "$TAG" > "$OUT/emission_traffic.log" 2>&1 && cp profiles/emission_traffic.json "$OUT/emission_traffic.json"
 echo "pmc done"
 stats config5 python3 profiles/config5_emission.py
 echo "config5 done"

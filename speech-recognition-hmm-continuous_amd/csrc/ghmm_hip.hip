@@ -74,6 +74,7 @@ struct ghmm_ctx {
     int *fix_mark = nullptr, *fix_list = nullptr, *fix_cnt = nullptr;
     size_t cap_fix_mark = 0, cap_fix_list = 0;
     int fix_stamp = 0;
+    long long launch_mark = 0, sync_mark = 0; // preparations enqueued / covered by a completed wait (stream_sync)
     bool loglik_pieces = false; // log P of the last E-step is in lpart / logk, loglik[] not assembled
     bool own_bwd_done = false; // k_scan_pair ran the backward direction for the current alpha
     bool beta_valid = false;   // ctx->beta holds the reference's beta^
@@ -109,6 +110,17 @@ struct ghmm_ctx {
     ktimer kt[GHMM_K_COUNT];
 };
 
+// every wait for the context's stream goes through here: what was enqueued before it has
+// completed, which run_accumulate uses to know whether the host's view of a model's statistics
+// flag (hflag_host) is up to date
+static hipError_t stream_sync(ghmm_ctx *ctx)
+{
+    const long long mark = ctx->launch_mark;
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) ctx->sync_mark = mark;
+    return e;
+}
+
 struct ghmm_model {
     int N = 0, M = 0, D = 0;
     double *A = nullptr, *c = nullptr, *mean = nullptr, *inv_var = nullptr, *det = nullptr;
@@ -136,6 +148,7 @@ struct ghmm_model {
     // between two exact paths, so a stale value costs time, never correctness.
     int *hflag_host = nullptr, *hflag_dev = nullptr;
     int vec_until = 0; // epoch up to which k_mixstats is launched unconditionally (after ghmm_model_set)
+    long long prep_mark = 0; // ctx->launch_mark when this model's current preparation was enqueued
     bool banded = false; // A as last set from the host has a_ij = 0 unless j = i or i + 1
     int epoch = 0; // preparation count; anyflag[0] == epoch: this model holds an ill-conditioned Gaussian
     int NE = 0, CT = 0; // statistics kernel: feature tiles, Gaussian tiles per wave
@@ -235,11 +248,11 @@ static int d2h_pageable(ghmm_ctx *ctx, void *dst, const void *src, size_t bytes,
 {
     if (bytes < (1u << 20) && !widen) {
         if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(stream_sync(ctx));
         return GHMM_OK;
     }
     if (bytes == 0) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(stream_sync(ctx));
         return GHMM_OK;
     }
     for (int k = 0; k < 2; k++)
@@ -267,7 +280,7 @@ static int d2h_pageable(ghmm_ctx *ctx, void *dst, const void *src, size_t bytes,
     }
     HIP_TRY(hipEventSynchronize(ctx->pin_ev[(k - 1) & 1]));
     chunk_out(dst, prev_off, ctx->pin[(k - 1) & 1], prev_n, widen);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -374,7 +387,7 @@ extern "C" int ghmm_ctx_sync(ghmm_ctx *ctx)
 {
     int rc = use(ctx);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -432,7 +445,7 @@ extern "C" int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value)
         if (rc) return rc;
         if (ctx->fix_cnt && ctx->fix_stamp > 0) {
             HIP_TRY(hipMemcpyAsync(&n, ctx->fix_cnt + (ctx->fix_stamp & 1), sizeof n, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(stream_sync(ctx));
         }
         *value = n;
         break;
@@ -449,7 +462,7 @@ extern "C" int ghmm_ctx_kernel_time(ghmm_ctx *ctx, int kernel, double *total_ms,
     int rc = use(ctx);
     if (rc) return rc;
     ARG_CHECK(kernel >= 0 && kernel < GHMM_K_COUNT, "kernel id out of range");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     ktimer &t = ctx->kt[kernel];
     for (auto &e : t.pending) {
         float ms = 0.f;
@@ -468,7 +481,7 @@ extern "C" int ghmm_ctx_kernel_time_reset(ghmm_ctx *ctx)
 {
     int rc = use(ctx);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     for (auto &t : ctx->kt) {
         for (auto &e : t.pending) t.pool.push_back(e);
         t.pending.clear();
@@ -482,7 +495,7 @@ extern "C" int ghmm_ctx_kernel_time_reset(ghmm_ctx *ctx)
 
 // preparations for which the vector-ALU statistics kernel stays launched after the host has
 // last seen (or could not yet have seen) a class-2 Gaussian
-constexpr int VEC_WINDOW = 4;
+constexpr int VEC_WINDOW = 64;
 
 static int model_prepare(ghmm_ctx *ctx, ghmm_model *m, bool base)
 {
@@ -577,7 +590,7 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
             // the host's late view of sflag (see ghmm_model): 64 bytes of pinned, mapped memory
             {
                 void *hp = nullptr, *dp = nullptr;
-                if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess ||
+                if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || // (fine-grained: a kernel's store is seen without a synchronisation)
                     hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
                     if (hp) (void)hipHostFree(hp);
                     ghmm_set_error("ghmm_model_create: no pinned host memory for the statistics flag");
@@ -658,11 +671,12 @@ extern "C" int ghmm_model_set(ghmm_ctx *ctx, ghmm_model *m, const double *A, con
     HIP_TRY(hipMemcpyAsync(m->inv_var, inv_var, G * m->D * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(m->det, det, G * 8, hipMemcpyHostToDevice, ctx->stream));
     // pageable host memory: the copies above have consumed the buffers on return
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     m->epoch++; // a new set of parameters
     // the host cannot know yet what this model's statistics classes are: k_mixstats is launched
     // (and leaves at once where it has nothing to do) for the first preparations behind this one
     m->vec_until = m->epoch + VEC_WINDOW;
+    m->prep_mark = ++ctx->launch_mark;
     return model_prepare(ctx, m, true);
 }
 
@@ -679,7 +693,7 @@ extern "C" int ghmm_model_get(ghmm_ctx *ctx, ghmm_model *m, double *A, double *c
     if (inv_var)
         HIP_TRY(hipMemcpyAsync(inv_var, m->inv_var, G * m->D * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (det) HIP_TRY(hipMemcpyAsync(det, m->det, G * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -857,7 +871,7 @@ extern "C" int ghmm_stats_download(ghmm_ctx *ctx, ghmm_stats *s, double *host)
     if (rc) return rc;
     ARG_CHECK(s && host, "null argument");
     HIP_TRY(hipMemcpyAsync(host, s->v, s->n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -868,7 +882,7 @@ extern "C" int ghmm_stats_loglik(ghmm_ctx *ctx, ghmm_stats *s, double out[2])
     ARG_CHECK(s && out, "null argument");
     // loglik and n_utt are the last two doubles of the vector (layout in ghmm.h)
     HIP_TRY(hipMemcpyAsync(out, s->v + (s->n - 2), 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -878,7 +892,7 @@ extern "C" int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *hos
     if (rc) return rc;
     ARG_CHECK(s && host, "null argument");
     HIP_TRY(hipMemcpyAsync(s->v, host, s->n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -1389,7 +1403,13 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     bool vec = P > 0;
     if (vec && mfma && G <= MS_MAXG) {
         const int seen = *(volatile int *)m->hflag_host;
-        vec = m->epoch <= m->vec_until || (m->epoch - seen) <= VEC_WINDOW;
+        if (ctx->sync_mark >= m->prep_mark)
+            vec = seen == m->epoch; // the preparation has completed (a wait covered it): the flag is current
+        else
+            // the host runs ahead of the device by an unknown number of iterations (a bench loop
+            // never waits): launch while a class-2 Gaussian was seen within the last VEC_WINDOW
+            // preparations or the model has come from the host that recently
+            vec = m->epoch <= m->vec_until || (m->epoch - seen) <= VEC_WINDOW;
         if (ctx->vec_stats) vec = ctx->vec_stats == 1;
     }
     if (vec) {
@@ -1533,6 +1553,7 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
     ARG_CHECK(m, "null model");
     if ((rc = check_stats(m, s))) return rc;
     m->epoch++; // a new set of parameters (and a new preparation of the matrix-core form)
+    m->prep_mark = ++ctx->launch_mark;
     // transitions are re-estimated inside the band i <= j <= i + delta only (TF:1601): a
     // band-diagonal A stays band-diagonal exactly when that band is i, i + 1
     m->banded = m->banded && ctx->delta <= 1;
@@ -1725,7 +1746,7 @@ extern "C" int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *
     if (c->U)
         HIP_TRY(hipMemcpyAsync(loglik_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,
                                ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -1831,7 +1852,7 @@ extern "C" int ghmm_score_streams(ghmm_ctx *ctx, ghmm_model *const *models, ghmm
     if ((rc = ws_fb(ctx, models[0], c)) || (rc = run_forward(ctx, models[0], c))) return rc;
     if (c->U)
         HIP_TRY(hipMemcpyAsync(loglik_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 
@@ -1979,7 +2000,7 @@ extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_
                                ctx->stream));
         if (c->F && (rc = d2h_pageable(ctx, path_host, ctx->path, (size_t)c->F, true))) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
 }
 

@@ -214,7 +214,7 @@ k_prepare_mfma(int N, int M, int D, int Mp, int NT, int DP, const double *__rest
         if (real && c0 > COND_MAX) anyflag[0] = epoch;
         if (scls[gp] == 2) {
             sflag[0] = epoch;
-            hflag[0] = epoch; // (host memory: tells the host, some time later, to launch k_mixstats)
+            __hip_atomic_store(hflag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (host memory: tells the host, some time later, to launch k_mixstats)
         }
     }
 }
@@ -325,7 +325,7 @@ k_mstep_mfma(int N, int M, int D, const double *__restrict__ stats, double norm2
             if (real && c0 > COND_MAX) anyflag[0] = epoch;
             if (cls == 2) {
                 sflag[0] = epoch;
-                hflag[0] = epoch; // (host memory, see k_prepare_mfma)
+                __hip_atomic_store(hflag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (host memory, see k_prepare_mfma)
             }
         }
     }
