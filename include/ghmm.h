@@ -101,7 +101,10 @@ enum {
      * Gaussian, and from an exact recomputation inside the reduction otherwise; 1 always
      * launch that kernel; 2 never (always the recomputation).  All three are exact; a
      * measurement / test switch. */
-    GHMM_OPT_VEC_STATS = 8
+    GHMM_OPT_VEC_STATS = 8,
+    /* mixture posteriors (gaus_probab_dens, TF:110) written with non-temporal stores: 0 (default)
+     * and 1 yes, 2 no.  Same bytes either way; a measurement switch (profiles/tools/nt_ab.py). */
+    GHMM_OPT_NT_POST = 9
 };
 int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value);
 int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value);

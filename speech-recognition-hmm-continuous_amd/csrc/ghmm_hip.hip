@@ -53,7 +53,7 @@ struct ghmm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int cus = 256, dev_cus = 256; // grid sizing (GHMM_OPT_CUS) / the device's count
-    int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0, vec_stats = 0;
+    int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0, vec_stats = 0, nt_post = 0;
     // workspace (grown on demand, never shrunk)
     size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
            cap_lognorm = 0, cap_loglik = 0, cap_pxi = 0, cap_pdena = 0, cap_pdenc = 0, cap_pmu = 0,
@@ -418,6 +418,10 @@ extern "C" int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value)
         ARG_CHECK(value >= 0 && value <= 2, "vec_stats must be 0, 1 or 2");
         ctx->vec_stats = value;
         break;
+    case GHMM_OPT_NT_POST:
+        ARG_CHECK(value >= 0 && value <= 2, "nt_post must be 0, 1 or 2");
+        ctx->nt_post = value;
+        break;
     case GHMM_OPT_CUS:
         ARG_CHECK(value >= 0 && value <= ctx->dev_cus, "compute units out of range");
         ctx->cus = value ? (int)value : ctx->dev_cus;
@@ -440,6 +444,7 @@ extern "C" int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value)
     case GHMM_OPT_PARTIALS: *value = ctx->partials; break;
     case GHMM_OPT_CUS: *value = ctx->cus; break;
     case GHMM_OPT_VEC_STATS: *value = ctx->vec_stats; break;
+    case GHMM_OPT_NT_POST: *value = ctx->nt_post; break;
     case GHMM_OPT_REFORDER_COUNT: {
         int n = 0, rc = use(ctx);
         if (rc) return rc;
@@ -1014,6 +1019,9 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         long long gxs = (ntf + wv - 1) / wv;
         if (gxs > ctx->cus) gxs = ctx->cus;
         const double *wk = mode == 2 ? m->logwkp : m->wkp; // OUT = 2 adds log wk to the exponents
+        // posteriors are written once and mostly never read (gamma is 0 for most states of a frame):
+        // non-temporal stores (see the kernel; GHMM_OPT_NT_POST 2 switches them off)
+        const int ntp = ctx->nt_post != 2;
         kscope ks(ctx, GHMM_K_EMISSION);
 #define GHMM_EMS(MP, PO)                                                                          \
     do {                                                                                          \
@@ -1021,7 +1029,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3((unsigned)(wv * WAVE)), lds_s, ctx->stream, m->N, m->M, m->D, m->NT, \
                            tcs, c->F, c->X, m->Wm, m->oglob, wk, m->gmap, ctx->b, post, m->dtile, \
-                           m->tshift, m->tfull, m->condt, m->mean, m->inv_var);                   \
+                           m->tshift, m->tfull, m->condt, m->mean, m->inv_var, ntp);              \
     } while (0)
 #define GHMM_EMS3(MP)                                                                             \
     do {                                                                                          \

@@ -527,7 +527,9 @@ constexpr int EMS_WAVES = 16;
 // Measurement builds only (profiles/tools/lab.sh compiles the library with -DGHMM_LAB=<bits> into
 // separate .so files; the product build leaves it 0): parts of k_emission_sched switched off so
 // that the rest can be timed on the hardware.  1: no exp, 2: no stores, 4: no MFMA chain,
-// 8: no state sums / reciprocal.
+// 8: no state sums / reciprocal; posterior stores 16: as whole lines from consecutive lanes (data
+// misplaced), 512: whole lines from lanes 8 apart (data misplaced), 128: into one 4 MB window (no HBM
+// writes).  Results: profiles/r3_lab_stores.txt.
 #ifndef GHMM_LAB
 #define GHMM_LAB 0
 #endif
@@ -808,8 +810,12 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                  double *__restrict__ b, double *__restrict__ post,
                  const double *__restrict__ dtile, const int *__restrict__ tshift,
                  const int *__restrict__ tfull, const double *__restrict__ condt,
-                 const double *__restrict__ mean, const double *__restrict__ inv_var)
-{
+                 const double *__restrict__ mean, const double *__restrict__ inv_var, int ntp)
+{   // ntp: posteriors leave with non-temporal stores.  Written once and mostly never read (gamma is 0
+    // for most states of a frame), they otherwise flush the 256 MB Infinity Cache of the frames, alpha^
+    // and W that the iteration's other kernels read again: 10x8 step 0.247 -> 0.235 ms, 64 mixtures
+    // 12.25 -> 12.15 (profiles/r3_lab_stores.txt, which also records what did NOT pay: whole 128-byte
+    // lines per store instruction need the lanes' data turned through LDS, and that costs what it gains)
     extern __shared__ double lds[];
     // slab row stride 2 * odd doubles: the 32 lanes of a ds_read_b64 group (16 frames x 2
     // k-columns) then fall on 32 different bank pairs
@@ -1222,10 +1228,26 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                                 double *pp = post + ((f0 + (l >> 3)) * G + gml[(ct + tt) * 16] + 2 * (l & 7));
                                 *(v2d *)pp = (v2d){pv[0], pv[1]};
                                 *(v2d *)(pp + 8 * G) = (v2d){pv[2], pv[3]};
+                            } else if (GHMM_LAB & 512) {
+                                // (lab: whole lines per instruction with the lanes of a line 8 apart: frames
+                                // j & 7 by the first store, 8 + (j & 7) by the second; data misplaced)
+                                double *pp = post + ((f0 + (j & 7)) * G + gml[(ct + tt) * 16] + 4 * kq + 2 * (j >> 3));
+                                *(v2d *)pp = (v2d){pv[0], pv[1]};
+                                *(v2d *)(pp + 8 * G) = (v2d){pv[2], pv[3]};
+                            } else if (GHMM_LAB & 128) {
+                                // (lab: every posterior store lands in one 4 MB window: L2 hits, no HBM writes)
+                                double *pp = post + ((fr * G + gml[(ct + tt) * 16 + 4 * kq]) & 0x7FFFFll);
+                                *(v2d *)pp = (v2d){pv[0], pv[1]};
+                                *(v2d *)(pp + 2) = (v2d){pv[2], pv[3]};
                             } else {
                             double *pp = post + (fr * G + gml[(ct + tt) * 16 + 4 * kq]);
-                            *(v2d *)pp = (v2d){pv[0], pv[1]};
-                            *(v2d *)(pp + 2) = (v2d){pv[2], pv[3]};
+                            if (ntp) {
+                                __builtin_nontemporal_store((v2d){pv[0], pv[1]}, (v2d *)pp);
+                                __builtin_nontemporal_store((v2d){pv[2], pv[3]}, (v2d *)(pp + 2));
+                            } else {
+                                *(v2d *)pp = (v2d){pv[0], pv[1]};
+                                *(v2d *)(pp + 2) = (v2d){pv[2], pv[3]};
+                            }
                             }
                         }
                     } else {
@@ -1475,7 +1497,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
 #pragma unroll
             for (int u = 0; u < NPL; u++) {
                 const unsigned o = ((smask >> pst[u]) & 1u) ? offp[u] - (unsigned)gmin : 0u;
-                rp[u] = *(const v2d *)(psrc + o);
+                rp[u] = *(const v2d *)(psrc + o); // (non-temporal loads here: -0.7 % at best, profiles/r3_lab_stores.txt)
             }
         };
         // MASKED: next stage >= from (< s1) with a state of this chunk in its mask, and that mask;
