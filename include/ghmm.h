@@ -103,7 +103,8 @@ enum {
      * measurement / test switch. */
     GHMM_OPT_VEC_STATS = 8,
     /* mixture posteriors (gaus_probab_dens, TF:110) written with non-temporal stores: 0 (default)
-     * and 1 yes, 2 no.  Same bytes either way; a measurement switch (profiles/tools/nt_ab.py). */
+     * when they are at most 1 GiB, 1 always, 2 never.  Same bytes either way; a measurement
+     * switch (profiles/tools/nt_ab.py). */
     GHMM_OPT_NT_POST = 9
 };
 int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value);

@@ -1020,8 +1020,12 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         if (gxs > ctx->cus) gxs = ctx->cus;
         const double *wk = mode == 2 ? m->logwkp : m->wkp; // OUT = 2 adds log wk to the exponents
         // posteriors are written once and mostly never read (gamma is 0 for most states of a frame):
-        // non-temporal stores (see the kernel; GHMM_OPT_NT_POST 2 switches them off)
-        const int ntp = ctx->nt_post != 2;
+        // non-temporal stores while an iteration's OTHER buffers can stay in the 256 MB Infinity Cache
+        // thanks to it (10x8, 192 MB of posteriors: 0.245 -> 0.232 ms per iteration); with 19 GB of
+        // them (64 mixtures) nothing stays anyway and the hint costs 0.4 %.  GHMM_OPT_NT_POST 1 / 2
+        // force it on / off (profiles/tools/nt_ab.py).
+        const int ntp = ctx->nt_post == 1 ||
+                        (ctx->nt_post == 0 && (double)c->F * m->N * m->M * 8.0 <= 1024.0 * 1048576.0);
         kscope ks(ctx, GHMM_K_EMISSION);
 #define GHMM_EMS(MP, PO)                                                                          \
     do {                                                                                          \

@@ -813,9 +813,10 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                  const double *__restrict__ mean, const double *__restrict__ inv_var, int ntp)
 {   // ntp: posteriors leave with non-temporal stores.  Written once and mostly never read (gamma is 0
     // for most states of a frame), they otherwise flush the 256 MB Infinity Cache of the frames, alpha^
-    // and W that the iteration's other kernels read again: 10x8 step 0.247 -> 0.235 ms, 64 mixtures
-    // 12.25 -> 12.15 (profiles/r3_lab_stores.txt, which also records what did NOT pay: whole 128-byte
-    // lines per store instruction need the lanes' data turned through LDS, and that costs what it gains)
+    // and W that the iteration's other kernels read again: 10x8 step 0.245 -> 0.232 ms; with 19 GB of
+    // them (64 mixtures) the host leaves it off (profiles/r3_lab_stores.txt, which also records what did
+    // NOT pay: whole 128-byte lines per store instruction need the lanes' data turned through LDS, and
+    // that costs what it gains)
     extern __shared__ double lds[];
     // slab row stride 2 * odd doubles: the 32 lanes of a ds_read_b64 group (16 frames x 2
     // k-columns) then fall on 32 different bank pairs
@@ -1242,6 +1243,9 @@ k_emission_sched(int N, int M, int D, int NT, int TC, long long F, const double 
                             } else {
                             double *pp = post + (fr * G + gml[(ct + tt) * 16 + 4 * kq]);
                             if (ntp) {
+                                // (the empty asm keeps the two arms apart: merged into one, hipcc
+                                // drops the hint and emits plain stores)
+                                asm volatile("" ::: "memory");
                                 __builtin_nontemporal_store((v2d){pv[0], pv[1]}, (v2d *)pp);
                                 __builtin_nontemporal_store((v2d){pv[2], pv[3]}, (v2d *)(pp + 2));
                             } else {
