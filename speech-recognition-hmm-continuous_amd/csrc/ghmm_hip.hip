@@ -985,6 +985,17 @@ static int ws_fb(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
 
 // --------------------------------------------------------------- emission
 
+static bool nt_posteriors(const ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
+{
+    // posteriors are written once and mostly never read (gamma is 0 for most states of a frame):
+    // non-temporal stores (emission) and loads (statistics) while an iteration's OTHER buffers can
+    // stay in the 256 MB Infinity Cache thanks to it (10x8, 192 MB of posteriors: 0.245 -> 0.230 ms
+    // per iteration); with 19 GB of them (64 mixtures) nothing stays anyway and the hint costs
+    // 0.4 %.  GHMM_OPT_NT_POST 1 / 2 force it on / off (profiles/tools/nt_ab.py).
+    return ctx->nt_post == 1 ||
+           (ctx->nt_post == 0 && (double)c->F * m->N * m->M * 8.0 <= 1024.0 * 1048576.0);
+}
+
 static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, bool want_post)
 {
     // the workspace is rewritten: alpha^ / W / 1/s of an earlier E-step no longer go with its b
@@ -1019,13 +1030,7 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         long long gxs = (ntf + wv - 1) / wv;
         if (gxs > ctx->cus) gxs = ctx->cus;
         const double *wk = mode == 2 ? m->logwkp : m->wkp; // OUT = 2 adds log wk to the exponents
-        // posteriors are written once and mostly never read (gamma is 0 for most states of a frame):
-        // non-temporal stores while an iteration's OTHER buffers can stay in the 256 MB Infinity Cache
-        // thanks to it (10x8, 192 MB of posteriors: 0.245 -> 0.232 ms per iteration); with 19 GB of
-        // them (64 mixtures) nothing stays anyway and the hint costs 0.4 %.  GHMM_OPT_NT_POST 1 / 2
-        // force it on / off (profiles/tools/nt_ab.py).
-        const int ntp = ctx->nt_post == 1 ||
-                        (ctx->nt_post == 0 && (double)c->F * m->N * m->M * 8.0 <= 1024.0 * 1048576.0);
+        const int ntp = nt_posteriors(ctx, m, c) ? 1 : 0; // non-temporal posterior stores
         kscope ks(ctx, GHMM_K_EMISSION);
 #define GHMM_EMS(MP, PO)                                                                          \
     do {                                                                                          \
@@ -1283,6 +1288,7 @@ extern "C" int ghmm_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
 template <int CT, int NE>
 static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int P, int chunks)
 {
+    const bool ntl = nt_posteriors(ctx, m, c); // (single-chunk launches only: small models)
     // fold buffer: four waves x half of the tiles (ghmm_mfma.hpp, end of k_mixstats_mfma)
     const size_t fold = (size_t)MSM_WAVES * ((CT * NE + 1) / 2) * 4 * 64 * sizeof(double);
     // staged variant: every chunk of CT tiles must map to an even-aligned, even-length run of
@@ -1297,6 +1303,7 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
         size_t lds = stage > fold ? stage : fold;
         int rc;
         if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true>))) return rc;
+        if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true, false, true>))) return rc;
         if (lds <= 150 * 1024) {
             // Several chunks (e.g. 64 mixtures: 8 chunks of little more than one state): each
             // chunk's launch walks only the stages in which one of its states is occupied, from
@@ -1325,10 +1332,16 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
                         continue;
                     }
                 }
-                hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true>), dim3((unsigned)P, 1u),
-                                   dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
-                                   m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
-                                   m->gmap + 0, m->oglob, ctx->part_m, (const unsigned *)nullptr);
+                if (ntl)
+                    hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true, false, true>), dim3((unsigned)P, 1u),
+                                       dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
+                                       m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
+                                       m->gmap + 0, m->oglob, ctx->part_m, (const unsigned *)nullptr);
+                else
+                    hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true>), dim3((unsigned)P, 1u),
+                                       dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
+                                       m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
+                                       m->gmap + 0, m->oglob, ctx->part_m, (const unsigned *)nullptr);
             }
             return GHMM_OK;
         }

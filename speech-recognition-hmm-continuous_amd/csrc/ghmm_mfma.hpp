@@ -1326,7 +1326,9 @@ constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 // Gaussians take several chunks (64 mixtures: 8 chunks of little more than one state each) most
 // stages of a chunk are empty, and an empty stage then costs a bit test instead of a trip to
 // memory.
-template <int CT, int NE, bool STAGED, bool MASKED = false>
+// NTL: the posteriors are read with non-temporal loads (compile time: behind a run-time flag hipcc
+// merges the two arms into one plain load)
+template <int CT, int NE, bool STAGED, bool MASKED = false, bool NTL = false>
 __global__ void __launch_bounds__(MSM_WAVES *WAVE, 1)
 k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gmin, int GW,
                 const double *__restrict__ X, const double *__restrict__ gamma,
@@ -1501,7 +1503,10 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
 #pragma unroll
             for (int u = 0; u < NPL; u++) {
                 const unsigned o = ((smask >> pst[u]) & 1u) ? offp[u] - (unsigned)gmin : 0u;
-                rp[u] = *(const v2d *)(psrc + o); // (non-temporal loads here: -0.7 % at best, profiles/r3_lab_stores.txt)
+                // NTL: the posteriors pass by once (the host picks this variant together with the
+                // emission kernel's non-temporal stores: -1 % per iteration at 10x8)
+                if (NTL) rp[u] = __builtin_nontemporal_load((const v2d *)(psrc + o));
+                else rp[u] = *(const v2d *)(psrc + o);
             }
         };
         // MASKED: next stage >= from (< s1) with a state of this chunk in its mask, and that mask;
