@@ -1462,9 +1462,17 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
 #pragma unroll
             for (int u = 0; u < NGL; u++)
                 bits |= (q[u][0] != 0.0 ? gb0[u] : 0u) | (q[u][1] != 0.0 ? gb1[u] : 0u);
-            unsigned m = 0;
-            for (int i = 0; i < N; i++) m |= (__ballot((bits >> i) & 1u) != 0ull ? 1u : 0u) << i;
-            return m;
+            // OR over the wave's lanes: four levels inside the rows of 16, then row 0 -> 1, 2 -> 3 and
+            // rows 0-1 -> 2-3 (row_bcast15 / row_bcast31), the total in lane 63 (a loop of one ballot
+            // per state took 110 instructions of a lone wave per stage: 13 % of the kernel)
+            int v = (int)bits;
+            v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+            v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+            v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); // row_half_mirror
+            v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true); // row_mirror
+            v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast15 into rows 1 and 3
+            v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast31 into rows 2 and 3
+            return (unsigned)__builtin_amdgcn_readlane(v, 63);
         };
         // where the two doubles of X piece u land: (slab offset << 8) | coefficient index
         unsigned xa[NXL], xb[NXL];
@@ -1495,8 +1503,9 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         // no state of the chunk in the mask: the frames' first piece as well)
         auto fetch = [&](long long stg, unsigned smask) {
             const long long f = stg * 16;
-            const v2d *xsrc = (const v2d *)(X + uniform64(f * D));
-            const double *psrc = post + uniform64(f * G + gmin);
+            // (lab 4096 / 2048: the frames / the posteriors from a 2 MB window: no HBM reads, same pattern)
+            const v2d *xsrc = (const v2d *)(X + uniform64((GHMM_LAB & 4096) ? ((f * D) & 0x3FFFEll) : f * D));
+            const double *psrc = post + uniform64((GHMM_LAB & 2048) ? ((f * G + gmin) & 0x3FFFEll) : f * G + gmin);
             const unsigned xm = (smask & cmask) != 0u ? ~0u : 0u; // wave-uniform
 #pragma unroll
             for (int u = 0; u < NXL; u++) rx[u] = xsrc[pcx[u] & xm];
@@ -1553,7 +1562,17 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
             for (int col = l; col < XS; col += WAVE) fx[r * XS + col] = col == D ? 1.0 : 0.0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (lab 8192: cycles of a wave spent waiting for its stage's loads / in the stage writer /
+        // issuing the next fetch / in the k-steps, printed by a few waves)
+        unsigned long long tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0, tst = 0;
+        const unsigned long long tbeg = (GHMM_LAB & 8192) ? __builtin_amdgcn_s_memtime() : 0ull;
         for (long long stg = MASKED ? cur : s0; stg < s1; stg = MASKED ? cur : stg + 1) {
+            unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+            if (GHMM_LAB & 8192) {
+                ta = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                tb = __builtin_amdgcn_s_memtime();
+            }
             if (MASKED || (smask_cur & cmask) != 0u) {
 #pragma unroll
                 for (int u = 0; u < NXL; u++) {
@@ -1569,6 +1588,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                 for (int u = 0; u < NGL; u++) ((v2d *)gs)[pcg[u]] = rg[u];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS is in order per wave
             }
+            if (GHMM_LAB & 8192) tc = __builtin_amdgcn_s_memtime();
             unsigned smask_next;
             if (MASKED) {
                 // the next occupied stage, in flight under this stage's MFMAs
@@ -1583,6 +1603,10 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
 #pragma unroll
                 for (int u = 0; u < NGL; u++) rg[u] = rgn[u];
                 fetch_gamma(stg + 2 < s1 ? stg + 2 : (stg + 1 < s1 ? stg + 1 : stg), rgn);
+            }
+            if (GHMM_LAB & 8192) {
+                td = __builtin_amdgcn_s_memtime();
+                tw0 += tb - ta; tw1 += tc - tb; tw2 += td - tc; tst++;
             }
             // Gaussian tiles with a state of this stage's mask
             unsigned tact = 0;
@@ -1635,6 +1659,13 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                 run(gB, pB, fB);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (GHMM_LAB & 8192) {
+            const unsigned long long tend = __builtin_amdgcn_s_memtime();
+            tw3 = (tend - tbeg) - tw0 - tw1 - tw2;
+            if (l == 0 && (blockIdx.x % 64) == 3 && gmin == 0)
+                printf("mixstats block %d wave %d: %llu stages, cycles total %llu: load wait %llu, stage writer %llu, fetch issue %llu, k-steps+rest %llu\n",
+                       (int)blockIdx.x, w, tst, tend - tbeg, tw0, tw1, tw2, tw3);
         }
         __syncthreads(); // the stages alias the fold buffer below
     } else
