@@ -656,6 +656,9 @@ __device__ const double EXP2_256[256] = {
 // ds_read_b64 group reads its own bank pair (or a broadcast); 256 entries conflict ~3-way on four
 // reads per tile and save two of twelve f64 instructions per value — the f64 pipe, which MFMA and
 // vector instructions share without overlap, is what the kernel is bound by.
+#ifndef GHMM_MIX_TILEMAJOR
+#define GHMM_MIX_TILEMAJOR 1 // statistics kernel: a stage's active tiles one after the other (0: k-step-major, round 2)
+#endif
 #ifndef GHMM_EXP_TAB
 #define GHMM_EXP_TAB 256
 #endif
@@ -1430,6 +1433,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         unsigned offp[NPL]; // posterior piece -> element offset inside a stage (rows strided by G)
         unsigned pcp[NPL], pcx[NXL], pcg[NGL]; // clamped piece indices
         unsigned pst[NPL];                     // state of the piece's two Gaussians (M even)
+        unsigned offpB[NPL], pbit[NPL], pcxB[NXL]; // byte offsets inside a stage, state bit, frame piece bytes
         unsigned gb0[NGL], gb1[NGL];           // state bits of the two gammas of a piece
 #pragma unroll
         for (int u = 0; u < NPL; u++) {
@@ -1440,6 +1444,8 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             divmod_small(pc, ppr, rppr, row, c2);
             offp[u] = (unsigned)(row * G + gmin + 2 * c2);
             pst[u] = (unsigned)((gmin + 2 * c2) / M);
+            offpB[u] = (offp[u] - (unsigned)gmin) * 8u;
+            pbit[u] = 1u << pst[u];
         }
 #pragma unroll
         for (int u = 0; u < NGL; u++) {
@@ -1481,6 +1487,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             int pc = l + 64 * u;
             pc = pc < nxp ? pc : nxp - 1;
             pcx[u] = (unsigned)pc;
+            pcxB[u] = (unsigned)pc * 16u;
             const int e0 = 2 * pc;
             int r0, d0;
             divmod_small(e0, D, rD, r0, d0);
@@ -1503,19 +1510,20 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         // no state of the chunk in the mask: the frames' first piece as well)
         auto fetch = [&](long long stg, unsigned smask) {
             const long long f = stg * 16;
-            // (lab 4096 / 2048: the frames / the posteriors from a 2 MB window: no HBM reads, same pattern)
-            const v2d *xsrc = (const v2d *)(X + uniform64((GHMM_LAB & 4096) ? ((f * D) & 0x3FFFEll) : f * D));
-            const double *psrc = post + uniform64((GHMM_LAB & 2048) ? ((f * G + gmin) & 0x3FFFEll) : f * G + gmin);
+            // wave-uniform bases in scalar registers + 32-bit per-lane BYTE offsets: the loads take the
+            // saddr + voffset form, no 64-bit address arithmetic per load
+            const char *xsrc = (const char *)(X + uniform64(f * D));
+            const char *psrc = (const char *)(post + uniform64(f * G + gmin));
             const unsigned xm = (smask & cmask) != 0u ? ~0u : 0u; // wave-uniform
 #pragma unroll
-            for (int u = 0; u < NXL; u++) rx[u] = xsrc[pcx[u] & xm];
+            for (int u = 0; u < NXL; u++) rx[u] = *(const v2d *)(xsrc + (size_t)(pcxB[u] & xm));
 #pragma unroll
             for (int u = 0; u < NPL; u++) {
-                const unsigned o = ((smask >> pst[u]) & 1u) ? offp[u] - (unsigned)gmin : 0u;
+                const unsigned o = (smask & pbit[u]) != 0u ? offpB[u] : 0u;
                 // NTL: the posteriors pass by once (the host picks this variant together with the
                 // emission kernel's non-temporal stores: -1 % per iteration at 10x8)
-                if (NTL) rp[u] = __builtin_nontemporal_load((const v2d *)(psrc + o));
-                else rp[u] = *(const v2d *)(psrc + o);
+                if (NTL) rp[u] = __builtin_nontemporal_load((const v2d *)(psrc + (size_t)o));
+                else rp[u] = *(const v2d *)(psrc + (size_t)o);
             }
         };
         // MASKED: next stage >= from (< s1) with a state of this chunk in its mask, and that mask;
@@ -1648,6 +1656,32 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                     }
             };
             if (tact == 0) continue; // nobody occupies any state of this chunk in these 16 frames
+            if (GHMM_MIX_TILEMAJOR) {
+                // Tile-major (round 3): the stage's 4 x NE frame operands are read once, then every
+                // ACTIVE Gaussian tile runs its four k-steps in one straight block — one branch per
+                // tile and stage.  The k-step-major order below tested every tile twice per k-step
+                // (operand reads, MFMAs): 40 branches per stage of a lone wave, and with the 1.35
+                // tiles that are active on average (gamma is 0 for 87 % of the pairs) more than half
+                // of the k-step phase was not matrix-pipe time (in-kernel stamps, GHMM_LAB 8192).
+                double fq[4][NE];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int n = 0; n < NE; n++) fq[q][n] = fxl[4 * q * XS + 16 * n];
+#pragma unroll
+                for (int c = 0; c < CT; c++)
+                    if ((tact >> c) & 1u) {
+                        double wq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) wq[q] = gsl[c][4 * q * N] * psl[c][4 * q * GW] * mk[c];
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+#pragma unroll
+                            for (int n = 0; n < NE; n++)
+                                acc[c][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(wq[q], fq[q][n], acc[c][n], 0, 0, 0);
+                    }
+                continue;
+            }
             rd(0, gA, pA, fA);
 #pragma unroll 1
             for (int h = 0; h < 2; h++) {
