@@ -1570,6 +1570,15 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
             for (int col = l; col < XS; col += WAVE) fx[r * XS + col] = col == D ? 1.0 : 0.0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the offsets of this lane's frame pieces, fixed for the whole kernel: in registers (the
+        // stage writer of a lone wave pays ~10 cycles per instruction, and ten LDS reads per stage
+        // for values that never change were 7 % of it)
+        double oa[NXL], ob[NXL];
+#pragma unroll
+        for (int u = 0; u < NXL; u++) {
+            oa[u] = ol[xa[u] & 255u];
+            ob[u] = ol[xb[u] & 255u];
+        }
         // (lab 8192: cycles of a wave spent waiting for its stage's loads / in the stage writer /
         // issuing the next fetch / in the k-steps, printed by a few waves)
         unsigned long long tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0, tst = 0;
@@ -1584,7 +1593,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             if (MASKED || (smask_cur & cmask) != 0u) {
 #pragma unroll
                 for (int u = 0; u < NXL; u++) {
-                    const double x0 = rx[u][0] - ol[xa[u] & 255u], x1 = rx[u][1] - ol[xb[u] & 255u];
+                    const double x0 = rx[u][0] - oa[u], x1 = rx[u][1] - ob[u];
                     fx[xa[u] >> 8] = x0;
                     fx[(xa[u] >> 8) + DP] = x0 * x0;
                     fx[xb[u] >> 8] = x1;
