@@ -75,6 +75,11 @@ struct ghmm_ctx {
     size_t cap_fix_mark = 0, cap_fix_list = 0;
     int fix_stamp = 0;
     long long launch_mark = 0, sync_mark = 0; // preparations enqueued / covered by a completed wait (stream_sync)
+    // one page of fine-grained pinned host memory, 64 slots of 64 bytes: the models' host-visible
+    // statistics flags (ghmm_model::hflag_host).  One allocation per context: hipHostMalloc takes
+    // milliseconds, a training job creates its model inside the time a user waits for.
+    int *hflag_page = nullptr, *hflag_page_dev = nullptr;
+    unsigned long long hflag_used = 0;
     bool loglik_pieces = false; // log P of the last E-step is in lpart / logk, loglik[] not assembled
     bool own_bwd_done = false; // k_scan_pair ran the backward direction for the current alpha
     bool beta_valid = false;   // ctx->beta holds the reference's beta^
@@ -147,6 +152,7 @@ struct ghmm_model {
     // is there after all, k_reduce_all recomputes it exactly itself — the flag only ever chooses
     // between two exact paths, so a stale value costs time, never correctness.
     int *hflag_host = nullptr, *hflag_dev = nullptr;
+    int hflag_slot = -1;
     int vec_until = 0; // epoch up to which k_mixstats is launched unconditionally (after ghmm_model_set)
     long long prep_mark = 0; // ctx->launch_mark when this model's current preparation was enqueued
     bool banded = false; // A as last set from the host has a_ij = 0 unless j = i or i + 1
@@ -371,6 +377,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
         if (p) (void)hipFree(p);
     for (double *p : ctx->post_s)
         if (p) (void)hipFree(p);
+    if (ctx->hflag_page) (void)hipHostFree(ctx->hflag_page);
     for (int k = 0; k < 2; k++) {
         if (ctx->pin[k]) (void)hipHostFree(ctx->pin[k]);
         if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
@@ -592,19 +599,36 @@ extern "C" int ghmm_model_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_model 
                 ghmm_model_destroy(ctx, m);
                 return rc;
             }
-            // the host's late view of sflag (see ghmm_model): 64 bytes of pinned, mapped memory
-            {
+            // the host's late view of sflag (see ghmm_model): a 64-byte slot of the context's page of
+            // pinned, mapped, fine-grained memory (a kernel's store is seen without a synchronisation)
+            if (!ctx->hflag_page) {
                 void *hp = nullptr, *dp = nullptr;
-                if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || // (fine-grained: a kernel's store is seen without a synchronisation)
+                if (hipHostMalloc(&hp, 4096, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                     hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
                     if (hp) (void)hipHostFree(hp);
-                    ghmm_set_error("ghmm_model_create: no pinned host memory for the statistics flag");
+                    ghmm_set_error("ghmm_model_create: no pinned host memory for the statistics flags");
                     ghmm_model_destroy(ctx, m);
                     return GHMM_ERR_ALLOC;
                 }
-                m->hflag_host = (int *)hp;
-                m->hflag_dev = (int *)dp;
-                m->hflag_host[0] = -(1 << 30); // no preparation has found a class-2 Gaussian
+                ctx->hflag_page = (int *)hp;
+                ctx->hflag_page_dev = (int *)dp;
+            }
+            {
+                int slot = 0;
+                while (slot < 64 && ((ctx->hflag_used >> slot) & 1ull)) slot++;
+                if (slot < 64) {
+                    ctx->hflag_used |= 1ull << slot;
+                    m->hflag_slot = slot;
+                    m->hflag_host = ctx->hflag_page + slot * 16;
+                    m->hflag_dev = ctx->hflag_page_dev + slot * 16;
+                    *(volatile int *)m->hflag_host = -(1 << 30); // no preparation has found a class-2 Gaussian
+                } else {
+                    // a vocabulary of more than 64 models on one context: this one goes without a
+                    // host-visible flag (the vector-ALU statistics kernel is then always launched
+                    // for it, as in round 2); the kernels' store lands on the device flag itself
+                    m->hflag_host = nullptr;
+                    m->hflag_dev = m->sflag;
+                }
             }
             // on the context's stream, like every consumer of these buffers
             hipError_t e = hipMemsetAsync(m->dtile, 0, (size_t)m->NT * m->DP * 8, ctx->stream);
@@ -654,7 +678,7 @@ extern "C" void ghmm_model_destroy(ghmm_ctx *ctx, ghmm_model *m)
                     m->logwkp, m->otile, m->dtile, m->condt, m->tshift, m->sflag, m->tnext, m->tfull, m->scls};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
-    if (m->hflag_host) (void)hipHostFree(m->hflag_host);
+    if (m->hflag_slot >= 0 && ctx) ctx->hflag_used &= ~(1ull << m->hflag_slot);
     delete m;
 }
 
@@ -1426,7 +1450,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     // just come from the host; otherwise left out (4.5 us of an idle 1 000-block launch per
     // iteration), and k_reduce_all recomputes a class-2 Gaussian exactly should one be there.
     bool vec = P > 0;
-    if (vec && mfma && G <= MS_MAXG) {
+    if (vec && mfma && G <= MS_MAXG && m->hflag_host) {
         const int seen = *(volatile int *)m->hflag_host;
         if (ctx->sync_mark >= m->prep_mark)
             vec = seen == m->epoch; // the preparation has completed (a wait covered it): the flag is current

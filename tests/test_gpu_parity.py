@@ -1627,3 +1627,22 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     c4 = rec["extras"]["config4"]
     assert c4["iterations"] == 10 and c4["checks_ok"] is True
     assert np.isfinite(rec["loglik_per_frame"])
+
+
+def test_more_models_than_flag_slots(G, ctx):
+    """A vocabulary of more than 64 models alive on one context (the context keeps one page of
+    pinned memory with 64 slots for the models' host-visible statistics flags): the models
+    beyond it work without one — E-step and M-step against the oracle on the 70th."""
+    hm, X, lens = synth_case(G, 6, 2, 9, [40, 33, 52])
+    models = [ctx.model(hm) for _ in range(70)]
+    corpus = ctx.corpus(X, lens)
+    stats = ctx.stats(6, 2, 9)
+    ref, _ = O.estep(hm, X, lens, dumps=False)
+    for m in (models[0], models[69]):
+        ctx.estep(m, corpus, stats)
+        assert_close(stats.download(), ref, what="statistics")
+        ctx.mstep(m, stats)
+        for a, b in zip(m.get().arrays(), O.mstep(hm, ref).arrays()):
+            assert_close(a, b, rtol=1e-7, what="model")
+    for o in models + [corpus, stats]:
+        o.close()
