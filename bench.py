@@ -181,8 +181,11 @@ def main():
     config4 = None
     want4 = args.config4 == "on" or (args.config4 == "auto" and world == 8)
     if world > 1 and want4:
-        config4 = config4_sharded(G, em, ctx, torch, dist, local, rank, world, stream,
-                                  args.config4_utts, barrier)
+        try:
+            config4 = config4_sharded(G, em, ctx, torch, dist, local, rank, world, stream,
+                                      args.config4_utts, barrier)
+        except Exception as e:   # noqa: BLE001 - the headline line must survive a failing extra
+            config4 = {"error": f"{type(e).__name__}: {e}"[:300], "checks_ok": False}
 
     if rank == 0:
         Gn = N * M
