@@ -1260,7 +1260,7 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
             ctx->last_c = c;
             ctx->slots = c->U * CB_CH;
         } else {
-            ++ctx->fix_stamp; // (no marks on this tier: a wave lists each of its utterances once)
+            if (++ctx->fix_stamp == 0x7fffffff) ctx->fix_stamp = 1; // (no marks on this tier: a wave lists each of its utterances once)
             int *cnt = ctx->fix_cnt + (ctx->fix_stamp & 1);
             if (L == 16)
                 hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,

@@ -529,7 +529,8 @@ constexpr int EMS_WAVES = 16;
 // that the rest can be timed on the hardware.  1: no exp, 2: no stores, 4: no MFMA chain,
 // 8: no state sums / reciprocal; posterior stores 16: as whole lines from consecutive lanes (data
 // misplaced), 512: whole lines from lanes 8 apart (data misplaced), 128: into one 4 MB window (no HBM
-// writes).  Results: profiles/r3_lab_stores.txt.
+// writes).  Results: profiles/r3_lab_stores.txt.  8192: cycle stamps (s_memtime) around the phases of a
+// wave of the statistics kernel, printed by a few waves (profiles/tools/stamp_run.py, profiles/r3_lab_mixstats.txt).
 #ifndef GHMM_LAB
 #define GHMM_LAB 0
 #endif
