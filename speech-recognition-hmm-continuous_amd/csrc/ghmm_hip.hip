@@ -1184,13 +1184,16 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_b
     return launch_ok("k_forward");
 }
 
+#ifndef GHMM_FIX_BLOCKS
+#define GHMM_FIX_BLOCKS 256u
+#endif
 // The utterances the pass before it listed (none on data a model fits), again, whole, in the
 // reference's own order of operations with its dense inner loops: one small launch that leaves
 // at once on an empty list.  spu = partial-sum slots per utterance of that pass.
 static int run_backward_fix(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int L, unsigned blocks, int spu,
                             const double *sinv)
 {
-    const unsigned fb = blocks < 256u ? blocks : 256u;
+    const unsigned fb = blocks < GHMM_FIX_BLOCKS ? blocks : GHMM_FIX_BLOCKS;
     int *cnt = ctx->fix_cnt + (ctx->fix_stamp & 1), *nxt = ctx->fix_cnt + ((ctx->fix_stamp + 1) & 1);
     if (L == 16)
         hipLaunchKernelGGL(k_backward_fix<16>, dim3(fb), dim3(WAVE), 0, ctx->stream, m->N, c->U, (int)ctx->delta,
