@@ -1131,9 +1131,18 @@ extern "C" int ghmm_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int w
 
 // ------------------------------------------------------- forward / backward
 
+// A statement once per group width, LL the width as a constant (template argument)
+#define GHMM_BY_LANES(L, ...)                                                                      \
+    do {                                                                                           \
+        if ((L) == 16) { constexpr int LL = 16; __VA_ARGS__; }                                     \
+        else if ((L) == 32) { constexpr int LL = 32; __VA_ARGS__; }                                \
+        else { constexpr int LL = 64; __VA_ARGS__; }                                               \
+    } while (0)
+
 static int fb_lanes(const ghmm_model *m, int *L)
 {
     if (m->N <= 16) *L = 16;
+    else if (m->N <= 32) *L = 32;
     else if (m->N <= 64) *L = 64;
     else {
         ghmm_set_error("%d states: the forward-backward kernels hold one state per lane (<= 64)",
@@ -1165,21 +1174,14 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_b
         if (use_pair(ctx)) {
             const unsigned ny = with_backward ? 2u : 1u;
             const int only = with_backward ? -1 : 0;
-            if (L == 16)
-                hipLaunchKernelGGL(k_scan_pair<16>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                                   only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
-                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
-            else
-                hipLaunchKernelGGL(k_scan_pair<64>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                                   only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
-                                   ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
+            GHMM_BY_LANES(L, hipLaunchKernelGGL(k_scan_pair<LL>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                                only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
+                                                ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order));
             ctx->own_bwd_done = with_backward;
-        } else if (L == 16)
-            hipLaunchKernelGGL(k_forward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink, c->order);
-        else
-            hipLaunchKernelGGL(k_forward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                               m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln, ctx->loglik, ctx->sink, c->order);
+        } else
+            GHMM_BY_LANES(L, hipLaunchKernelGGL(k_forward<LL>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                                m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
+                                                ctx->loglik, ctx->sink, c->order));
     }
     return launch_ok("k_forward");
 }
@@ -1195,14 +1197,10 @@ static int run_backward_fix(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int L,
 {
     const unsigned fb = blocks < GHMM_FIX_BLOCKS ? blocks : GHMM_FIX_BLOCKS;
     int *cnt = ctx->fix_cnt + (ctx->fix_stamp & 1), *nxt = ctx->fix_cnt + ((ctx->fix_stamp + 1) & 1);
-    if (L == 16)
-        hipLaunchKernelGGL(k_backward_fix<16>, dim3(fb), dim3(WAVE), 0, ctx->stream, m->N, c->U, (int)ctx->delta,
-                           m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta, ctx->gamma, ctx->part_xi,
-                           ctx->part_dena, ctx->part_denc, ctx->sink, cnt, ctx->fix_list, nxt, spu, sinv);
-    else
-        hipLaunchKernelGGL(k_backward_fix<64>, dim3(fb), dim3(WAVE), 0, ctx->stream, m->N, c->U, (int)ctx->delta,
-                           m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta, ctx->gamma, ctx->part_xi,
-                           ctx->part_dena, ctx->part_denc, ctx->sink, cnt, ctx->fix_list, nxt, spu, sinv);
+    GHMM_BY_LANES(L, hipLaunchKernelGGL(k_backward_fix<LL>, dim3(fb), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                        (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta,
+                                        ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, cnt,
+                                        ctx->fix_list, nxt, spu, sinv));
     return launch_ok("k_backward_fix");
 }
 
@@ -1221,14 +1219,10 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
         kscope ks(ctx, GHMM_K_BACKWARD);
         if (use_pair(ctx)) {
             if (!ctx->own_bwd_done) { // the forward pass ran alone (row API): the other direction now
-                if (L == 16)
-                    hipLaunchKernelGGL(k_scan_pair<16>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream, m->N,
-                                       c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
-                else
-                    hipLaunchKernelGGL(k_scan_pair<64>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream, m->N,
-                                       c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                       (const double *)nullptr, ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order);
+                GHMM_BY_LANES(L, hipLaunchKernelGGL(k_scan_pair<LL>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream,
+                                                    m->N, c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
+                                                    ctx->sinv, (const double *)nullptr, ctx->loglik, ctx->wrow,
+                                                    ctx->sb, ctx->sink, c->order));
                 ctx->own_bwd_done = true;
             }
             const unsigned cb = (unsigned)(((long long)c->U * CB_CH + gpw - 1) / gpw);
@@ -1247,15 +1241,12 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
                 HIP_TRY(hipMemsetAsync(ctx->fix_cnt, 0, 2 * sizeof(int), ctx->stream));
                 ctx->fix_stamp = 1;
             }
-            if (L == 16 && band2) {
-                if (want_beta) GHMM_COMBINE(16, true, false);
-                else GHMM_COMBINE(16, false, false);
-            } else if (L == 16) {
-                if (want_beta) GHMM_COMBINE(16, true, true);
-                else GHMM_COMBINE(16, false, true);
+            if (band2) {
+                if (want_beta) GHMM_BY_LANES(L, GHMM_COMBINE(LL, true, false));
+                else GHMM_BY_LANES(L, GHMM_COMBINE(LL, false, false));
             } else {
-                if (want_beta) GHMM_COMBINE(64, true, true);
-                else GHMM_COMBINE(64, false, true);
+                if (want_beta) GHMM_BY_LANES(L, GHMM_COMBINE(LL, true, true));
+                else GHMM_BY_LANES(L, GHMM_COMBINE(LL, false, true));
             }
             if ((rc = run_backward_fix(ctx, m, c, L, blocks, CB_CH, nullptr))) return rc;
             ctx->beta_valid = want_beta;
@@ -1265,16 +1256,10 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
         } else {
             if (++ctx->fix_stamp == 0x7fffffff) ctx->fix_stamp = 1; // (no marks on this tier: a wave lists each of its utterances once)
             int *cnt = ctx->fix_cnt + (ctx->fix_stamp & 1);
-            if (L == 16)
-                hipLaunchKernelGGL(k_backward<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                                   (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order,
-                                   cnt, ctx->fix_list);
-            else
-                hipLaunchKernelGGL(k_backward<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
-                                   (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv,
-                                   ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena, ctx->part_denc, ctx->sink, c->order,
-                                   cnt, ctx->fix_list);
+            GHMM_BY_LANES(L, hipLaunchKernelGGL(k_backward<LL>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                                (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
+                                                ctx->sinv, ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena,
+                                                ctx->part_denc, ctx->sink, c->order, cnt, ctx->fix_list));
             // utterances whose band-only update met an overflowed beta^: again, dense (TF:1493-1510)
             if ((rc = run_backward_fix(ctx, m, c, L, blocks, 1, ctx->sinv))) return rc;
             ctx->beta_valid = true;
@@ -1996,17 +1981,12 @@ extern "C" int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_
         return GHMM_OK;
     }
     {
-        const int L = Nmax <= 16 ? 16 : 64, gpw = WAVE / L;
+        const int L = Nmax <= 16 ? 16 : Nmax <= 32 ? 32 : 64, gpw = WAVE / L;
         const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
         kscope ks(ctx, GHMM_K_FORWARD);
-        if (L == 16)
-            hipLaunchKernelGGL(k_forward_multi<16>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
-                               ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
-                               ctx->sink, c->order);
-        else
-            hipLaunchKernelGGL(k_forward_multi<64>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
-                               ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
-                               ctx->sink, c->order);
+        GHMM_BY_LANES(L, hipLaunchKernelGGL(k_forward_multi<LL>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
+                                            ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
+                                            ctx->sink, c->order));
     }
     rc = launch_ok("k_forward_multi");
     if (!rc) {
@@ -2040,12 +2020,9 @@ extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_
         const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
         {
             kscope ks(ctx, GHMM_K_VITERBI);
-            if (L == 16)
-                hipLaunchKernelGGL(k_viterbi<16>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
-                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, ctx->sink, c->order);
-            else
-                hipLaunchKernelGGL(k_viterbi<64>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N,
-                                   c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik, ctx->sink, c->order);
+            GHMM_BY_LANES(L, hipLaunchKernelGGL(k_viterbi<LL>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
+                                                m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik,
+                                                ctx->sink, c->order));
         }
         if ((rc = launch_ok("k_viterbi"))) return rc;
         HIP_TRY(hipMemcpyAsync(score_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,

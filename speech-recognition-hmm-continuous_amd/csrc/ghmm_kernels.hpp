@@ -160,11 +160,11 @@ k_mul_streams(long long n, double *__restrict__ b, const double *__restrict__ bp
 }
 
 // ------------------------------------------------------------ group helpers
-// A "group" is L consecutive lanes (L = 16 or 64) that own one utterance, lane i =
+// A "group" is L consecutive lanes (L = 16, 32 or 64) that own one utterance, lane i =
 // state i.  Cross-lane traffic stays inside the group.
-// For L = 16 a group is one DPP row: shifts and the butterfly sum are register moves
-// (v_mov_b32_dpp), not LDS-crossbar shuffles (ds_bpermute) — they sit on the serial
-// critical path of every time step.
+// For L = 16 a group is one DPP row; wider groups span rows.  Shifts and the butterfly sum
+// are register moves (v_mov_b32_dpp, v_permlane*_swap), not LDS-crossbar shuffles
+// (ds_bpermute) — they sit on the serial critical path of every time step.
 template <int CTRL> __device__ inline double dpp_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -185,33 +185,53 @@ __device__ inline double dpp_xor4_f64(double v)
 constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111;
 constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
 
+// wave_shr:1 / wave_shl:1 (the GFX9 whole-wave DPP shifts): lane i-1 / i+1 across the rows, 0 at the
+// wave's ends
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
+// sum of v over the row pairs {0,1}, {2,3} (v_permlane16_swap with both operands the same value
+// hands every lane its own row's and the partner row's value) / over the two halves of the wave
+__device__ inline double rows_pair_sum(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+__device__ inline double halves_pair_sum(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+
 template <int L> __device__ inline double group_sum(double v)
 {
-    if (L == 16) {
-        // rotate-and-add: every lane of the row ends with the same bits (each level adds
-        // the same unordered pair on both partners)
-        v += dpp_f64<DPP_ROW_ROR8>(v);
-        v += dpp_f64<DPP_ROW_ROR4>(v);
-        v += dpp_f64<DPP_ROW_ROR2>(v);
-        v += dpp_f64<DPP_ROW_ROR1>(v);
-        return v;
-    }
-#pragma unroll
-    for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, L);
+    // rotate-and-add inside a 16-lane row: every lane of the row ends with the same bits (each
+    // level adds the same unordered pair on both partners); wider groups then add the rows
+    // pairwise with the lane-swap instructions, again the same unordered pair in every lane.
+    // All of it is register moves (v_mov_b32_dpp / v_permlane*_swap), not LDS-crossbar
+    // shuffles: the sum sits on the serial critical path of every time step.
+    v += dpp_f64<DPP_ROW_ROR8>(v);
+    v += dpp_f64<DPP_ROW_ROR4>(v);
+    v += dpp_f64<DPP_ROW_ROR2>(v);
+    v += dpp_f64<DPP_ROW_ROR1>(v);
+    if (L >= 32) v = rows_pair_sum(v);
+    if (L >= 64) v = halves_pair_sum(v);
     return v;
 }
 // value of lane i-1 (0 for the first lane of the group) / lane i+1 (0 for the last)
 template <int L> __device__ inline double group_up1(double v)
 {
     if (L == 16) return dpp_f64<DPP_ROW_SHR1>(v);
-    double r = __shfl_up(v, 1, L);
-    return (threadIdx.x % L) ? r : 0.0;
+    const double r = dpp_f64<DPP_WAVE_SHR1>(v);
+    return (L == WAVE || (threadIdx.x % L)) ? r : 0.0;
 }
 template <int L> __device__ inline double group_down1(double v)
 {
     if (L == 16) return dpp_f64<DPP_ROW_SHL1>(v);
-    double r = __shfl_down(v, 1, L);
-    return (threadIdx.x % L) != L - 1 ? r : 0.0;
+    const double r = dpp_f64<DPP_WAVE_SHL1>(v);
+    return (L == WAVE || (threadIdx.x % L) != L - 1) ? r : 0.0;
 }
 // sum over the Mp (power of two <= 16) adjacent lanes that hold one state's mixtures
 constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141,
