@@ -1304,18 +1304,18 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
     // fold buffer: four waves x half of the tiles (ghmm_mfma.hpp, end of k_mixstats_mfma)
     const size_t fold = (size_t)MSM_WAVES * ((CT * NE + 1) / 2) * 4 * 64 * sizeof(double);
     // staged variant: every chunk of CT tiles must map to an even-aligned, even-length run of
-    // real Gaussians (true when no mixture padding: Mp == M, M even) and N <= 16
+    // real Gaussians (true when no mixture padding: Mp == M, M even) and N <= 32 (two 16-byte
+    // gamma pieces per lane and stage up to 16 states, four beyond)
     const int G = m->N * m->M;
     const bool staged = (((unsigned long long)c->X) & 15ull) == 0 && // (its frame pieces are 16-byte loads)
-                        m->Mp == m->M && (m->M % 2) == 0 && m->N <= 16 && (G % 2) == 0 &&
+                        m->Mp == m->M && (m->M % 2) == 0 && m->N <= 32 && (G % 2) == 0 &&
                         ((CT * 16) % 2) == 0 && ctx->kernels != 3;
+    const bool wide = m->N > 16;
+    int rc;
     if (staged) {
         const int GWmax = CT * 16 < G ? CT * 16 : G;
         size_t stage = (size_t)MSM_WAVES * (16 * (NE * 16 + GWmax + m->N) + m->DP) * sizeof(double);
         size_t lds = stage > fold ? stage : fold;
-        int rc;
-        if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true>))) return rc;
-        if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true, false, true>))) return rc;
         if (lds <= 150 * 1024) {
             // Several chunks (e.g. 64 mixtures: 8 chunks of little more than one state): each
             // chunk's launch walks only the stages in which one of its states is occupied, from
@@ -1325,40 +1325,38 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
                 if (chunks > 1 && c->F >= 16) {
                     const size_t nst = (size_t)((c->F + 15) / 16);
                     if ((rc = dev_grow(&ctx->smask, &ctx->cap_smask, nst))) return rc;
-                    if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, true, true>))) return rc;
                     hipLaunchKernelGGL(k_stage_masks, dim3((unsigned)((c->F + WAVE - 1) / WAVE)), dim3(WAVE), 0,
                                        ctx->stream, m->N, c->F, ctx->gamma, ctx->smask);
                     masked = true;
                 }
             }
+#define GHMM_MIXSTATS(...)                                                                         \
+    do {                                                                                           \
+        if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<__VA_ARGS__>))) return rc;          \
+        hipLaunchKernelGGL((k_mixstats_mfma<__VA_ARGS__>), dim3((unsigned)P, 1u), dim3(MSM_WAVES * WAVE), lds,  \
+                           ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, \
+                           ctx->post, m->gmap + 0, m->oglob, ctx->part_m,                          \
+                           masked ? ctx->smask : (const unsigned *)nullptr);                       \
+    } while (0)
             // one launch per chunk so that gmin / GW are plain arguments (chunks == 1 at 10x8)
             for (int ch = 0; ch < chunks; ch++) {
                 const int gmin = ch * CT * 16;
-                int GW = G - gmin < CT * 16 ? G - gmin : CT * 16;
+                const int GW = G - gmin < CT * 16 ? G - gmin : CT * 16;
                 if constexpr (NE == 5) {
                     if (masked) {
-                        hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true, true>), dim3((unsigned)P, 1u),
-                                           dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
-                                           m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
-                                           m->gmap + 0, m->oglob, ctx->part_m, ctx->smask);
+                        if (wide) GHMM_MIXSTATS(CT, NE, true, true, false, 4);
+                        else GHMM_MIXSTATS(CT, NE, true, true);
                         continue;
                     }
                 }
-                if (ntl)
-                    hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true, false, true>), dim3((unsigned)P, 1u),
-                                       dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
-                                       m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
-                                       m->gmap + 0, m->oglob, ctx->part_m, (const unsigned *)nullptr);
-                else
-                    hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, true>), dim3((unsigned)P, 1u),
-                                       dim3(MSM_WAVES * WAVE), lds, ctx->stream, m->N, m->M, m->Mp, m->D,
-                                       m->DP, m->NT, c->F, gmin, GW, c->X, ctx->gamma, ctx->post,
-                                       m->gmap + 0, m->oglob, ctx->part_m, (const unsigned *)nullptr);
+                if (wide) GHMM_MIXSTATS(CT, NE, true, false, false, 4);
+                else if (ntl) GHMM_MIXSTATS(CT, NE, true, false, true);
+                else GHMM_MIXSTATS(CT, NE, true);
             }
+#undef GHMM_MIXSTATS
             return GHMM_OK;
         }
     }
-    int rc;
     if ((rc = lds_attr(ctx, (const void *)k_mixstats_mfma<CT, NE, false>))) return rc;
     hipLaunchKernelGGL((k_mixstats_mfma<CT, NE, false>), dim3((unsigned)P, (unsigned)chunks),
                        dim3(MSM_WAVES * WAVE), fold, ctx->stream, m->N, m->M, m->Mp, m->D, m->DP, m->NT,

@@ -1337,7 +1337,8 @@ constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
 // STAGED = true: frames go HBM -> registers -> LDS in 16-frame stages with fully
 // coalesced 16-byte-per-lane loads (one stage ahead), MFMA operands come from LDS.
-// Needs G, gmin, GW even (16-byte alignment of the posterior rows) and N <= 16.
+// Needs G, gmin, GW even (16-byte alignment of the posterior rows) and N <= 8 NGL (<= 32: the
+// state masks are 32-bit words).
 // STAGED = false: operands straight from HBM, 8 bytes per lane (any shape).
 // MASKED (staged only): the states that carry weight in every 16-frame stage come from
 // smask[stage] (k_stage_masks) instead of from gamma travelling a stage ahead, and the wave
@@ -1347,7 +1348,8 @@ constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 // memory.
 // NTL: the posteriors are read with non-temporal loads (compile time: behind a run-time flag hipcc
 // merges the two arms into one plain load)
-template <int CT, int NE, bool STAGED, bool MASKED = false, bool NTL = false>
+// NGL: 16-byte gamma pieces per lane and stage (2: N <= 16, 4: N <= 32)
+template <int CT, int NE, bool STAGED, bool MASKED = false, bool NTL = false, int NGL = 2>
 __global__ void __launch_bounds__(MSM_WAVES *WAVE, 1)
 k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gmin, int GW,
                 const double *__restrict__ X, const double *__restrict__ gamma,
@@ -1432,10 +1434,10 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         // been issued, so that the kernel's set-up runs under their HBM latency)
         const double og_l = l < D ? oglob[l] : 0.0, og_h = l + WAVE < D ? oglob[l + WAVE < D ? l + WAVE : 0] : 0.0;
         // 16-byte pieces moved per stage: X 8*D, posteriors 8*GW, gamma 8*N; lane l takes
-        // pieces l + 64u.  Bounds: 8*D <= 64*NE, 8*GW <= 64*2*CT, 8*N <= 64*2.  Surplus lanes
+        // pieces l + 64u.  Bounds: 8*D <= 64*NE, 8*GW <= 64*2*CT, 8*N <= 64*NGL.  Surplus lanes
         // repeat the last piece, load and store alike (same value to the same place): no
         // predicates, no branches in the stage writer.
-        constexpr int NXL = NE, NPL = 2 * CT, NGL = 2;
+        constexpr int NXL = NE, NPL = 2 * CT;
         const int nxp = 8 * D, npp = 8 * GW, ngp = 8 * N, ppr = GW / 2;
         const float rD = 1.0f / (float)D, rppr = 1.0f / (float)ppr;
         // gamma is EXACTLY 0 for most (frame, state) pairs (alpha^ beta^ underflows away from the
