@@ -403,10 +403,18 @@ def side_measurements(G, em, ctx, torch, dev, mean, std, start, corpus, kavg, Xh
     model = ctx.model(start)
     be = em.HipBackend(G, ctx, model, cr)
     drv = em.EMDriver(be)
-    wall, kt = _timed_steps(ctx, G, drv.step, 10)
+    # measured like the fixed-length corpus beside it: 30 untimed iterations, 60 timed (ten
+    # iterations straight after the change of corpus read 12 % slower than the kernels are)
+    wall, kt = _timed_steps(ctx, G, drv.step, 60, warmup=30)
     fr = int(lens.sum())
+    mf = ctx.model(start)
+    bf = em.HipBackend(G, ctx, mf, corpus)
+    wall_f, _ = _timed_steps(ctx, G, em.EMDriver(bf).step, 60, warmup=30)
+    bf.stats.close(); mf.close()
     out["ragged"] = {"workload": "T ~ U[100, 500], 1 000 utterances", "frames": fr,
                      "ms_per_step": rnd(wall), "frames_per_s": rnd(fr / (wall * 1e-3), 1),
+                     "fixed_length_ms_per_step": rnd(wall_f),
+                     "per_frame_vs_fixed_length": rnd((wall / fr) / (wall_f / corpus.frames), 3),
                      "scan_ms": rnd(kt.get("forward", 0) + kt.get("backward", 0)),
                      "fixed_length_scan_ms": rnd((kavg.get("forward") or 0) + (kavg.get("backward") or 0))}
     out["ragged"]["checks_ok"] = _stats_checks(G, be.stats.download(), N, M, D, fr, len(lens))
