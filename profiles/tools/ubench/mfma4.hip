@@ -71,6 +71,18 @@ __global__ void k_lat(double *out, unsigned long long *cyc, double x)
                 s += dpp_f64<0x124>(s);
                 s += dpp_f64<0x122>(s);
                 s += dpp_f64<0x121>(s);
+            } else if (MODE == 2) {
+                // two stages of three independent DPP reads of the same register
+                const double d1 = dpp_f64<0xB1>(v), d2 = dpp_f64<0x4E>(v), d3 = dpp_f64<0x1B>(v);
+                const double q = (v + d1) + (d2 + d3);
+                const double e1 = dpp_f64<0x141>(q), e2 = dpp_f64<0x128>(q), e3 = dpp_f64<0x140>(q);
+                s = (q + e1) + (e2 + e3);
+            } else if (MODE == 3) {
+                // quad stage 4-way, then two binary levels
+                const double d1 = dpp_f64<0xB1>(v), d2 = dpp_f64<0x4E>(v), d3 = dpp_f64<0x1B>(v);
+                s = (v + d1) + (d2 + d3);
+                s += dpp_f64<0x124>(s);
+                s += dpp_f64<0x128>(s);
             } else {
                 const double r1 = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f64_4x4x4f64(r1, 1.0, 0.0, 0, 0, 0);
@@ -111,5 +123,11 @@ int main()
     for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_lat<1>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
     hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
     printf("mfma 16-lane sum + 2 dependent ops: %.1f cycles per round\n", (double)hc / (64.0 * 32));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_lat<2>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
+    hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+    printf("two 4-way dpp stages + 2 dependent ops: %.1f cycles per round\n", (double)hc / (64.0 * 32));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_lat<3>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
+    hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+    printf("4-way quad stage + 2 binary levels + 2 dependent ops: %.1f cycles per round\n", (double)hc / (64.0 * 32));
     return 0;
 }
