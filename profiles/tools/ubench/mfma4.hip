@@ -55,6 +55,17 @@ template <int CTRL> __device__ inline double dpp_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+__global__ void k_bcsum(double *out)
+{
+    const int l = threadIdx.x;
+    const double v = (double)(1 << (l & 15)) + (l >> 4) * 65536.0, one = 1.0;
+    double s = 0.0;
+    asm volatile("s_nop 1" ::: "memory");
+#define BC0(K) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v), "v"(one));
+    BC0(0) BC0(1) BC0(2) BC0(3) BC0(4) BC0(5) BC0(6) BC0(7) BC0(8) BC0(9) BC0(10) BC0(11) BC0(12) BC0(13) BC0(14) BC0(15)
+    out[l] = s;
+}
+
 template <int MODE>
 __global__ void k_lat(double *out, unsigned long long *cyc, double x)
 {
@@ -71,6 +82,15 @@ __global__ void k_lat(double *out, unsigned long long *cyc, double x)
                 s += dpp_f64<0x124>(s);
                 s += dpp_f64<0x122>(s);
                 s += dpp_f64<0x121>(s);
+            } else if (MODE == 4 || MODE == 5) {
+                // serial chain of v_fmac_f64 with a DPP row broadcast of lane k as its first factor
+                constexpr int NS = MODE == 4 ? 10 : 16;
+                const double one = 1.0;
+                s = 0.0;
+                asm volatile("s_nop 1" ::: "memory");
+#define BC(K) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v), "v"(one));
+                BC(0) BC(1) BC(2) BC(3) BC(4) BC(5) BC(6) BC(7) BC(8) BC(9)
+                if (NS == 16) { BC(10) BC(11) BC(12) BC(13) BC(14) BC(15) }
             } else if (MODE == 2) {
                 // two stages of three independent DPP reads of the same register
                 const double d1 = dpp_f64<0xB1>(v), d2 = dpp_f64<0x4E>(v), d3 = dpp_f64<0x1B>(v);
@@ -123,6 +143,19 @@ int main()
     for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_lat<1>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
     hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
     printf("mfma 16-lane sum + 2 dependent ops: %.1f cycles per round\n", (double)hc / (64.0 * 32));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_lat<4>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
+    hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+    printf("10 fmac_dpp row_newbcast + 2 dependent ops: %.1f cycles per round\n", (double)hc / (64.0 * 32));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_lat<5>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
+    hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+    printf("16 fmac_dpp row_newbcast + 2 dependent ops: %.1f cycles per round\n", (double)hc / (64.0 * 32));
+    {   // correctness: lane l holds 2^(l & 15) + row * 65536 -> every lane of a row = 65535 + 16 * 65536 * row
+        hipLaunchKernelGGL(k_bcsum, dim3(1), dim3(64), 0, 0, out);
+        hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
+        printf("bcast sum by lane:");
+        for (int l = 0; l < 64; l += 5) printf(" %.0f", h[l]);
+        printf("\n");
+    }
     for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_lat<2>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
     hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
     printf("two 4-way dpp stages + 2 dependent ops: %.1f cycles per round\n", (double)hc / (64.0 * 32));
