@@ -45,7 +45,7 @@ enum {
     GHMM_ERR_ALLOC = 2,       /* host or device allocation failed */
     GHMM_ERR_HIP = 3,         /* a HIP runtime call failed */
     GHMM_ERR_NODEVICE = 4,    /* no usable gfx950 device */
-    GHMM_ERR_UNSUPPORTED = 5, /* valid request outside what is built (e.g. more than 64 states in the recursions) */
+    GHMM_ERR_UNSUPPORTED = 5, /* valid request outside what is built (e.g. more than 512 states in the recursions) */
     GHMM_ERR_IO = 6,          /* file could not be opened / read / written */
     GHMM_ERR_FORMAT = 7       /* file content is not a .perfil / .hmm */
 };
@@ -204,7 +204,10 @@ int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *host);
  * within-state mixture posteriors `gauss[i][j]`, TF:1773-1778) and RF:860-947
  * (want_post = 0).  Results stay in the context workspace. */
 int ghmm_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int want_post);
-/* calc_alpha TF:1380-1443 / RF:739-799 + calc_probability TF:1536-1553 */
+/* calc_alpha TF:1380-1443 / RF:739-799 + calc_probability TF:1536-1553.
+ * Models of up to 512 states (the reference's cap is 20, TF:41): one state per lane up to 64,
+ * one wave per utterance with the states strided over its lanes beyond (GHMM_ERR_UNSUPPORTED
+ * above 512; ghmm_viterbi: 255, its back-pointers are bytes). */
 int ghmm_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c);
 /* calc_beta TF:1463-1516, fused with the per-utterance part of
  * calc_transition_probab TF:1577-1620 and calc_den_mix_coef TF:1642-1664 */

@@ -19,9 +19,13 @@ run harsh_strict python3 profiles/fuzz_oracle.py 600 harsh
 run wharsh_strict python3 profiles/fuzz_oracle.py 400 wide harsh
 run short        python3 profiles/fuzz_oracle.py 600 short
 run wide_short   python3 profiles/fuzz_oracle.py 300 wide short
+run huge         python3 profiles/fuzz_oracle.py 300 huge
+run huge_harsh   python3 profiles/fuzz_oracle.py 200 huge harsh subnormal
+run huge_short   python3 profiles/fuzz_oracle.py 200 huge short
 run tiers        python3 profiles/fuzz_tiers.py 300
 run viterbi      python3 profiles/fuzz_viterbi.py 600
 run viterbi_h    python3 profiles/fuzz_viterbi.py 600 harsh
+run viterbi_huge python3 profiles/fuzz_viterbi.py 200 huge
 run train        python3 profiles/fuzz_train.py 300 10
 run streams      python3 profiles/fuzz_streams.py 200
 run batch        python3 profiles/fuzz_batch.py 300

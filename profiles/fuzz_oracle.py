@@ -12,7 +12,7 @@ import test_gpu_parity as T
 G = load_pkg().ghmm
 ctx = G.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-wide = "wide" in sys.argv[2:]
+wide = "huge" if "huge" in sys.argv[2:] else "wide" in sys.argv[2:]   # huge: 65 .. 255 states (ghmm_wide.hpp)
 harsh = "harsh" in sys.argv[2:]
 short = "short" in sys.argv[2:]
 subnormal = "subnormal" in sys.argv[2:]   # statistics below 1e-300 compared absolutely, their quotients not at all
@@ -28,7 +28,7 @@ for seed in range(n):
     except AssertionError as e:
         bad += 1
         print(str(e)[:240])
-print(f"{n} {'wide ' if wide else ''}{'harsh ' if harsh else ''}{'short ' if short else ''}shapes against the oracle, {bad} disagreements" + (f", {skipped} skipped (reference not finite)" if harsh or short else "")
+print(f"{n} {'huge ' if wide == 'huge' else 'wide ' if wide else ''}{'harsh ' if harsh else ''}{'short ' if short else ''}shapes against the oracle, {bad} disagreements" + (f", {skipped} skipped (reference not finite)" if harsh or short else "")
       + f"; {reordered} agreeing shapes had utterances taken again in the reference's order")
 
 if which and (harsh or "list" in sys.argv[2:]):

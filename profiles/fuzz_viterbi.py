@@ -10,7 +10,7 @@ import test_gpu_parity as T
 G = load_pkg().ghmm
 ctx = G.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-wide = "wide" in sys.argv[2:]
+wide = "huge" if "huge" in sys.argv[2:] else "wide" in sys.argv[2:]   # huge: 65 .. 255 states (ghmm_wide.hpp)
 harsh = "harsh" in sys.argv[2:]
 bad = utts = 0
 for seed in range(n):
@@ -19,4 +19,4 @@ for seed in range(n):
     except AssertionError as e:
         bad += 1
         print(str(e)[:240])
-print(f"{n} {'wide ' if wide else ''}shapes, {utts} utterances, {bad} differ")
+print(f"{n} {'huge ' if wide == 'huge' else 'wide ' if wide else ''}shapes, {utts} utterances, {bad} differ")

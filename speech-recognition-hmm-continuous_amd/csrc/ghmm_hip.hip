@@ -18,6 +18,7 @@
 #include "ghmm_kernels.hpp"
 #include "ghmm_mfma.hpp"
 #include "ghmm_pair.hpp"
+#include "ghmm_wide.hpp"
 
 extern "C" void ghmm_set_error(const char *fmt, ...); // ghmm_io.c
 
@@ -72,6 +73,7 @@ struct ghmm_ctx {
     // stamped with the pass number, the list, and two counters used alternately (the fix-up
     // kernel of pass n zeroes the counter of pass n + 1)
     int *fix_mark = nullptr, *fix_list = nullptr, *fix_cnt = nullptr;
+    int *wide_flag = nullptr; // models of more than 64 states: A (or log A) has entries off the band
     size_t cap_fix_mark = 0, cap_fix_list = 0;
     int fix_stamp = 0;
     long long launch_mark = 0, sync_mark = 0; // preparations enqueued / covered by a completed wait (stream_sync)
@@ -372,7 +374,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
                     ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb,
                     ctx->lpart,   ctx->logk,      ctx->b_stream,  ctx->smask,
-                    ctx->fix_mark, ctx->fix_list, ctx->fix_cnt};
+                    ctx->fix_mark, ctx->fix_list, ctx->fix_cnt, ctx->wide_flag};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     for (double *p : ctx->post_s)
@@ -1140,38 +1142,61 @@ extern "C" int ghmm_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int w
     } while (0)
 
 static int fb_lanes(const ghmm_model *m, int *L)
-{
+{   // L = 0: more states than lanes, the one-wave-per-utterance kernels of ghmm_wide.hpp
     if (m->N <= 16) *L = 16;
     else if (m->N <= 32) *L = 32;
     else if (m->N <= 64) *L = 64;
+    else if (m->N <= WIDE_MAX) *L = 0;
     else {
-        ghmm_set_error("%d states: the forward-backward kernels hold one state per lane (<= 64)",
-                       m->N);
+        ghmm_set_error("%d states: the forward / backward / Viterbi kernels take models of up to %d",
+                       m->N, WIDE_MAX);
         return GHMM_ERR_UNSUPPORTED;
     }
     return GHMM_OK;
 }
 
+// models of more than 64 states: is A (zero = 0) or log A (zero = -inf) band-diagonal?  Decided on
+// the device at every pass (the M-step may have changed it), read by the wide kernels behind it.
+static int wide_band_flag(ghmm_ctx *ctx, const ghmm_model *m, const double *A, double zero)
+{
+    int rc;
+    if (!ctx->wide_flag && (rc = dev_alloc(&ctx->wide_flag, 1))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->wide_flag, 0, sizeof(int), ctx->stream));
+    const long long n = (long long)m->N * m->N;
+    hipLaunchKernelGGL(k_wide_band, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m->N, A, zero,
+                       ctx->wide_flag);
+    return launch_ok("k_wide_band");
+}
+
 // The paired scans of ghmm_pair.hpp unless GHMM_OPT_KERNELS = 1 asks for the reference's order
 // (calc_alpha, then calc_beta scaled by its c_t) in the one-pass kernels.
-static bool use_pair(const ghmm_ctx *ctx) { return ctx->kernels != 1; }
+static bool use_pair(const ghmm_ctx *ctx, const ghmm_model *m) { return ctx->kernels != 1 && m->N <= 64; }
 
 static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_backward = false)
 {
     if (c->U == 0) return GHMM_OK;
     int L, rc;
     if ((rc = fb_lanes(m, &L))) return rc;
-    const int gpw = WAVE / L;
-    const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
     const double *ln = ctx->robust ? ctx->lognorm : nullptr;
     ctx->last_m = nullptr; // alpha^ is rewritten: run_backward re-arms these
     ctx->last_c = nullptr;
     ctx->own_bwd_done = false;
     ctx->beta_valid = false;
-    ctx->loglik_pieces = use_pair(ctx) && with_backward; // k_combine will take the logs
+    if (L == 0) { // more than 64 states: one wave per utterance, the reference's order (ghmm_wide.hpp)
+        ctx->loglik_pieces = false;
+        if ((rc = wide_band_flag(ctx, m, m->A, 0.0))) return rc;
+        kscope ks(ctx, GHMM_K_FORWARD);
+        hipLaunchKernelGGL(k_forward_wide, dim3((unsigned)c->U), dim3(WAVE), (size_t)4 * m->N * sizeof(double),
+                           ctx->stream, m->N, c->U, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
+                           ctx->loglik, c->order, ctx->wide_flag, m->N, (const double *)nullptr);
+        return launch_ok("k_forward_wide");
+    }
+    const int gpw = WAVE / L;
+    const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
+    ctx->loglik_pieces = use_pair(ctx, m) && with_backward; // k_combine will take the logs
     {
         kscope ks(ctx, GHMM_K_FORWARD);
-        if (use_pair(ctx)) {
+        if (use_pair(ctx, m)) {
             const unsigned ny = with_backward ? 2u : 1u;
             const int only = with_backward ? -1 : 0;
             GHMM_BY_LANES(L, hipLaunchKernelGGL(k_scan_pair<LL>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
@@ -1213,11 +1238,22 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
     }
     int L, rc;
     if ((rc = fb_lanes(m, &L))) return rc;
+    if (L == 0) {
+        if ((rc = wide_band_flag(ctx, m, m->A, 0.0))) return rc;
+        kscope ks(ctx, GHMM_K_BACKWARD);
+        hipLaunchKernelGGL(k_backward_wide, dim3((unsigned)c->U), dim3(WAVE),
+                           (size_t)(4 + MAX_DELTA + 1) * m->N * sizeof(double), ctx->stream, m->N, c->U,
+                           (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta, ctx->gamma,
+                           ctx->part_xi, ctx->part_dena, ctx->part_denc, c->order, ctx->wide_flag);
+        ctx->beta_valid = true;
+        ctx->slots = c->U;
+        return launch_ok("k_backward_wide");
+    }
     const int gpw = WAVE / L;
     const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
     {
         kscope ks(ctx, GHMM_K_BACKWARD);
-        if (use_pair(ctx)) {
+        if (use_pair(ctx, m)) {
             if (!ctx->own_bwd_done) { // the forward pass ran alone (row API): the other direction now
                 GHMM_BY_LANES(L, hipLaunchKernelGGL(k_scan_pair<LL>, dim3(blocks, 1u), dim3(WAVE), 0, ctx->stream,
                                                     m->N, c->U, 1, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
@@ -1913,11 +1949,12 @@ extern "C" int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_
         ghmm_set_error("models have %d coefficients per frame, corpus has %d", D, c->D);
         return GHMM_ERR_ARG;
     }
-    if (Nmax > 64) {
-        ghmm_set_error("%d states: the forward kernel holds one state per lane (<= 64)", Nmax);
-        return GHMM_ERR_UNSUPPORTED;
-    }
     if (c->U == 0) return GHMM_OK;
+    if (Nmax > 64) { // the one-launch vocabulary loop holds one state per lane: word by word instead
+        for (int k = 0; k < n_models; k++)
+            if ((rc = ghmm_score(ctx, models[k], c, loglik_host + (size_t)k * c->U))) return rc;
+        return GHMM_OK;
+    }
     // the concatenated model: NS states x M mixtures (transition matrix unused)
     ghmm_model *cat = nullptr;
     if ((rc = ghmm_model_create(ctx, NS, M, D, &cat))) return rc;
@@ -2010,13 +2047,19 @@ extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_
     if ((rc = fb_lanes(m, &L))) return rc;
     ARG_CHECK(m->N <= 255, "too many states for byte back-pointers");
     if ((rc = ws_frames(ctx, m, c, false))) return rc;
-    if ((rc = dev_grow(&ctx->psi, &ctx->cap_psi, (size_t)c->F * L + 16))) return rc; // rows of L bytes
+    if ((rc = dev_grow(&ctx->psi, &ctx->cap_psi, (size_t)c->F * (L ? L : m->N) + 16))) return rc; // rows of L (N) bytes
     if ((rc = dev_grow(&ctx->path, &ctx->cap_path, (size_t)c->F))) return rc;
     if ((rc = run_emission(ctx, m, c, 2, false))) return rc;
     if (c->U) {
-        const int gpw = WAVE / L;
+        const int gpw = L ? WAVE / L : 1;
         const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
-        {
+        if (L == 0) {
+            if ((rc = wide_band_flag(ctx, m, m->logA, -INFINITY))) return rc;
+            kscope ks(ctx, GHMM_K_VITERBI);
+            hipLaunchKernelGGL(k_viterbi_wide, dim3(blocks), dim3(WAVE), (size_t)2 * m->N * sizeof(double),
+                               ctx->stream, m->N, c->U, m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik,
+                               c->order, ctx->wide_flag);
+        } else {
             kscope ks(ctx, GHMM_K_VITERBI);
             GHMM_BY_LANES(L, hipLaunchKernelGGL(k_viterbi<LL>, dim3(blocks), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                                 m->logA, ctx->b, c->off, ctx->psi, ctx->path, ctx->loglik,

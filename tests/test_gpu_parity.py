@@ -839,6 +839,9 @@ def fuzz_shape(rng, wide):
     scheduled emission kernel serves."""
     if not wide:
         return int(rng.integers(1, 21)), int(rng.integers(1, 12)), int(rng.integers(1, 45))
+    if wide == "huge":   # more states than a wave has lanes (ghmm_wide.hpp), small Gaussians
+        return (int(rng.choice([65, 80, 100, 128, 129, 200, 255])), int(rng.choice([1, 2, 3, 4])),
+                int(rng.choice([1, 3, 8, 13])))
     N = int(rng.choice([1, 2, 3, 5, 10, 16, 17, 31, 32, 48, 64]))
     M = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 24, 32, 33, 64]))
     D = int(rng.integers(36, 41)) if rng.integers(0, 2) else int(rng.choice([1, 8, 13, 26, 45, 52, 64]))
@@ -860,7 +863,7 @@ def fuzz_estep_case(G, ctx, seed, wide=False, harsh=False, short=False, subnorma
     (1e-316 .. 5e-324: a handful of bits, different in any two implementations, the reference's
     own -O0 and -O2 builds included).  Statistics below 1e-300 are then compared absolutely
     (to 1e-300), and the M-step's quotients of such statistics are not compared."""
-    rng = np.random.default_rng((19000 if wide else 9000) + seed)
+    rng = np.random.default_rng((29000 if wide == "huge" else 19000 if wide else 9000) + seed)
     N, M, D = fuzz_shape(rng, wide)
     # every utterance can reach the last state (short: utterances of 1 .. N + 30 frames, some
     # shorter than the model — no path into the last state, gamma = xi = 0 as in the reference)
@@ -939,7 +942,7 @@ def fuzz_viterbi_case(G, ctx, seed, wide=False, harsh=False):
     """Viterbi state sequences (bit-identical) and forward scores against the oracle on one
     seeded random shape; profiles/fuzz_viterbi.py runs it over more seeds.  Returns the number
     of utterances checked."""
-    rng = np.random.default_rng((17000 if wide else 7000) + seed)
+    rng = np.random.default_rng((27000 if wide == "huge" else 17000 if wide else 7000) + seed)
     N, M, D = fuzz_shape(rng, wide)
     lens = [int(x) for x in rng.integers(1, 150, size=int(rng.integers(1, 6)))]
     dense = bool(rng.integers(0, 2))
@@ -978,6 +981,60 @@ def test_fuzz_estep_against_oracle(G, ctx, seed):
 @pytest.mark.parametrize("seed", list(range(20)))
 def test_fuzz_viterbi_against_oracle(G, ctx, seed):
     fuzz_viterbi_case(G, ctx, seed)
+
+
+# Models of 65 .. 255 states: one wave per utterance, states strided over its lanes (ghmm_wide.hpp)
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_fuzz_estep_more_states_than_lanes(G, ctx, seed):
+    fuzz_estep_case(G, ctx, seed, wide="huge")
+
+
+@pytest.mark.parametrize("seed", list(range(4)))
+def test_fuzz_estep_more_states_than_lanes_short(G, ctx, seed):
+    fuzz_estep_case(G, ctx, seed, wide="huge", short=True)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzz_viterbi_more_states_than_lanes(G, ctx, seed):
+    fuzz_viterbi_case(G, ctx, seed, wide="huge")
+
+
+def test_vocabulary_with_a_model_of_more_states_than_lanes(G, ctx):
+    """ghmm_score_batch falls back to the word-by-word loop when a model has more than 64 states."""
+    hms = []
+    X = lens = None
+    for k, N in enumerate((5, 70, 12)):
+        hm, Xk, lk = synth_case(G, N, 2, 6, [90, 75, 130], seed=40 + k)
+        hms.append(hm)
+        if k == 1:
+            X, lens = Xk, lk
+    models = [ctx.model(hm) for hm in hms]
+    corpus = ctx.corpus(X, lens)
+    try:
+        got = ctx.score_batch(models, corpus)
+        o = 0
+        for u, Tn in enumerate(lens):
+            for k, hm in enumerate(hms):
+                ref = O.score(hm, X[o:o + Tn])
+                assert (np.isnan(ref) and np.isnan(got[k, u])) or got[k, u] == ref or \
+                    abs(got[k, u] - ref) <= 1e-10 * abs(ref), (k, u, got[k, u], ref)
+            o += Tn
+    finally:
+        for m_ in models:
+            m_.close()
+        corpus.close()
+
+
+def test_more_states_than_the_wide_kernels_take_is_refused(G, ctx):
+    hm, X, lens = synth_case(G, 513, 1, 2, [520])
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    try:
+        with pytest.raises(G.GhmmError) as e:
+            ctx.score(model, corpus)
+        assert "states" in str(e.value)
+    finally:
+        model.close()
+        corpus.close()
 
 
 # (433 and 555: single-mixture models whose far states have SUBNORMAL densities — the posterior
