@@ -33,5 +33,7 @@ run options      python3 profiles/fuzz_options.py 200
 run threads      python3 profiles/fuzz_threads.py 80
 run init         python3 profiles/fuzz_init.py 300
 run robust       python3 profiles/fuzz_robust.py 300
+run train_huge   python3 profiles/fuzz_train.py 60 6 huge
+run init_huge    python3 profiles/fuzz_init.py 60 huge
 run train_big    python3 profiles/fuzz_train.py 60 8 big
 cat "$OUT/summary.txt"

@@ -3,7 +3,8 @@ bit-exact) followed by K fixed EM iterations on the GPU — against the oracle's
 corpora.  From that model components collapse onto single frames within a few iterations
 (variances at the 1e-5 floor), which is where the statistics classes, the per-tile offsets and the
 direct-form band of the emission kernel come into play.
-usage: fuzz_train.py [n_seeds] [iterations = 6] [big]   (big: 16 / 32 mixtures, several chunks of Gaussians)"""
+usage: fuzz_train.py [n_seeds] [iterations = 6] [big | huge]   (big: 16 / 32 mixtures, several chunks of
+Gaussians; huge: 17 .. 200 states, the 32- and 64-lane groups and the one-wave-per-utterance kernels)"""
 import sys
 import numpy as np
 sys.path.insert(0, "tests")
@@ -22,6 +23,8 @@ for seed in range(n):
     N = int(rng.integers(2, 11)); M = int(rng.choice([1, 2, 3, 4, 8])); D = int(rng.choice([5, 9, 13, 36, 39, 40]))
     if big:
         N = int(rng.integers(4, 17)); M = int(rng.choice([16, 32])); D = int(rng.choice([36, 39]))
+    if "huge" in sys.argv[3:]:
+        N = int(rng.choice([17, 20, 32, 33, 64, 65, 100, 200])); M = int(rng.choice([1, 2, 4])); D = int(rng.choice([5, 9, 13]))
     lens = np.asarray([int(x) for x in rng.integers(2 * N + 10, 2 * N + 90, size=int(rng.integers(3, 14)))], dtype=np.int32)
     if big:   # enough frames for every cell of the initial codebook
         lens = np.asarray([int(x) for x in rng.integers(3 * N * M // 4, N * M + 60, size=int(rng.integers(6, 14)))], dtype=np.int32)
