@@ -105,7 +105,12 @@ enum {
     /* mixture posteriors (gaus_probab_dens, TF:110) written with non-temporal stores: 0 (default)
      * when they are at most 1 GiB, 1 always, 2 never.  Same bytes either way; a measurement
      * switch (profiles/tools/nt_ab.py). */
-    GHMM_OPT_NT_POST = 9
+    GHMM_OPT_NT_POST = 9,
+    /* ghmm_estep's recursions: both scans and the gamma / xi pass in ONE launch (a block scans its
+     * utterances with two waves, then all of its waves take the chunks) whenever A is band-diagonal
+     * — 0 (default) and 1; 2 = the separate launches.  Same operations either way; a measurement
+     * switch (profiles/tools/fused_ab.py). */
+    GHMM_OPT_FUSED_SCAN = 10
 };
 int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value);
 int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value);

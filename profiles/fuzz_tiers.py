@@ -30,6 +30,18 @@ for seed in range(n):
         out[tier] = dict(stats=stats.download(), gamma=ctx.fetch(G.BUF_GAMMA, (F, N)),
                          beta=ctx.fetch(G.BUF_BETA, (F, N)), ll=ctx.fetch(G.BUF_LOGLIK, (len(lens),)))
         stats.close()
+    # the default tier with its recursions in separate launches (GHMM_OPT_FUSED_SCAN 2): bit for bit
+    ctx.set_option(G.OPT_FUSED_SCAN, 2)
+    stats = ctx.stats(N, M, D)
+    ctx.estep(model, corpus, stats)
+    sep = dict(stats=stats.download(), gamma=ctx.fetch(G.BUF_GAMMA, (F, N)),
+               beta=ctx.fetch(G.BUF_BETA, (F, N)), ll=ctx.fetch(G.BUF_LOGLIK, (len(lens),)))
+    stats.close()
+    ctx.set_option(G.OPT_FUSED_SCAN, 0)
+    for k in ("ll", "gamma", "beta", "stats"):
+        if not np.array_equal(out[0][k], sep[k], equal_nan=True):
+            bad += 1
+            print(f"seed {seed}: N={N} M={M} D={D} lens={list(lens)} dense={dense} delta={delta} robust={robust}: {k}: one launch and separate launches differ")
     for k in ("ll", "gamma", "beta", "stats"):
         try:
             T.assert_close(out[0][k], out[1][k], rtol=1e-9, what=k)

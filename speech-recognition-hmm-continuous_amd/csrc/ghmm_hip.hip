@@ -54,7 +54,7 @@ struct ghmm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int cus = 256, dev_cus = 256; // grid sizing (GHMM_OPT_CUS) / the device's count
-    int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0, vec_stats = 0, nt_post = 0;
+    int64_t delta = 1, robust = 0, kernels = 0, timing = 0, partials = 0, vec_stats = 0, nt_post = 0, fused_scan = 0;
     // workspace (grown on demand, never shrunk)
     size_t cap_b = 0, cap_post = 0, cap_alpha = 0, cap_beta = 0, cap_gamma = 0, cap_scale = 0,
            cap_lognorm = 0, cap_loglik = 0, cap_pxi = 0, cap_pdena = 0, cap_pdenc = 0, cap_pmu = 0,
@@ -427,6 +427,10 @@ extern "C" int ghmm_ctx_set_option(ghmm_ctx *ctx, int option, int64_t value)
         ARG_CHECK(value >= 0 && value <= 2, "vec_stats must be 0, 1 or 2");
         ctx->vec_stats = value;
         break;
+    case GHMM_OPT_FUSED_SCAN:
+        ARG_CHECK(value >= 0 && value <= 2, "fused_scan must be 0, 1 or 2");
+        ctx->fused_scan = value;
+        break;
     case GHMM_OPT_NT_POST:
         ARG_CHECK(value >= 0 && value <= 2, "nt_post must be 0, 1 or 2");
         ctx->nt_post = value;
@@ -454,6 +458,7 @@ extern "C" int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value)
     case GHMM_OPT_CUS: *value = ctx->cus; break;
     case GHMM_OPT_VEC_STATS: *value = ctx->vec_stats; break;
     case GHMM_OPT_NT_POST: *value = ctx->nt_post; break;
+    case GHMM_OPT_FUSED_SCAN: *value = ctx->fused_scan; break;
     case GHMM_OPT_REFORDER_COUNT: {
         int n = 0, rc = use(ctx);
         if (rc) return rc;
@@ -1305,6 +1310,49 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
     return launch_ok("k_backward");
 }
 
+// ghmm_estep on a band-diagonal A: forward, backward and the gamma / xi pass in one launch
+// (k_scan_combine; never slower than the separate launches, 1 000 .. 12 500 utterances measured:
+// profiles/tools/fused_ab.py).  Returns GHMM_OK with *done = false when the separate launches apply.
+static int run_scan_combine(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool *done)
+{
+    *done = false;
+    int L, rc;
+    if (c->U == 0 || !use_pair(ctx, m) || ctx->fused_scan == 2) return GHMM_OK;
+    if ((rc = fb_lanes(m, &L))) return rc;
+    const bool band2 = m->banded && ctx->delta <= 1;
+    const int gpw = WAVE / L;
+    const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
+    if (!band2) return GHMM_OK;
+    ctx->own_bwd_done = true;
+    ctx->loglik_pieces = true; // the combine phase takes the logs of log P
+    if (++ctx->fix_stamp == 0x7fffffff) { // (2^31 passes: start the marks over)
+        HIP_TRY(hipMemsetAsync(ctx->fix_mark, 0, ctx->cap_fix_mark * sizeof(int), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->fix_cnt, 0, 2 * sizeof(int), ctx->stream));
+        ctx->fix_stamp = 1;
+    }
+    {
+        kscope ks(ctx, GHMM_K_FORWARD);
+        GHMM_BY_LANES(L, hipLaunchKernelGGL((k_scan_combine<LL, false>), dim3(blocks), dim3(CB_CH * WAVE), 0, ctx->stream,
+                                            m->N, c->U, (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
+                                            ctx->wrow, ctx->sb, ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena,
+                                            ctx->part_denc, ctx->sink,
+                                            ctx->robust ? ctx->lognorm : (const double *)nullptr, ctx->lpart, ctx->logk,
+                                            c->order, ctx->fix_mark, ctx->fix_stamp, ctx->fix_cnt + (ctx->fix_stamp & 1),
+                                            ctx->fix_list));
+    }
+    if ((rc = launch_ok("k_scan_combine"))) return rc;
+    {
+        kscope ks(ctx, GHMM_K_BACKWARD);
+        if ((rc = run_backward_fix(ctx, m, c, L, blocks, CB_CH, nullptr))) return rc;
+    }
+    ctx->beta_valid = false; // beta^ on demand (ghmm_fetch)
+    ctx->last_m = m;
+    ctx->last_c = c;
+    ctx->slots = c->U * CB_CH;
+    *done = true;
+    return GHMM_OK;
+}
+
 static int need_emission(ghmm_ctx *ctx, const ghmm_model *m, const ghmm_corpus *c)
 {
     if (!ctx->b || ctx->F != c->F || ctx->U != c->U || ctx->N != m->N || ctx->b_is_log ||
@@ -1611,8 +1659,12 @@ extern "C" int ghmm_estep(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     if (rc || (rc = check_pair(m, c)) || (rc = check_stats(m, s))) return rc;
     if ((rc = ws_frames(ctx, m, c, true)) || (rc = ws_fb(ctx, m, c))) return rc;
     if ((rc = run_emission(ctx, m, c, ctx->robust ? 1 : 0, true))) return rc;
-    if ((rc = run_forward(ctx, m, c, true))) return rc;
-    if ((rc = run_backward(ctx, m, c, false))) return rc; // beta^ on demand (ghmm_fetch)
+    bool fused = false;
+    if ((rc = run_scan_combine(ctx, m, c, &fused))) return rc;
+    if (!fused) {
+        if ((rc = run_forward(ctx, m, c, true))) return rc;
+        if ((rc = run_backward(ctx, m, c, false))) return rc; // beta^ on demand (ghmm_fetch)
+    }
     return run_accumulate(ctx, m, c, s);
 }
 

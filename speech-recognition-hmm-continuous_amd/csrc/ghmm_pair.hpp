@@ -309,9 +309,10 @@ __device__ __forceinline__ bool combine_run(int N, int T, int delta, int i, bool
 // DENSE = false: A is known (on the host, ghmm_model_set) to be band-diagonal with a_ij = 0
 // unless j = i or i + 1, only that form is compiled (half the registers, twice the waves in
 // flight); DENSE = true decides per wave on the device like the one-pass kernels.
+// group qs = (utterance in length order, chunk), lane i of the group
 template <int L, bool WANT_BETA, bool DENSE>
-__global__ void __launch_bounds__(WAVE, DENSE ? 2 : 4)
-k_combine(int N, int U, int delta, const double *__restrict__ A, const long long *__restrict__ off,
+__device__ __forceinline__ void combine_group(int qs, int i, int N, int U, int delta, const double *__restrict__ A,
+          const long long *__restrict__ off,
           const double *__restrict__ alpha, const double *__restrict__ scale,
           const double *__restrict__ wrow, const double *__restrict__ sb, double *__restrict__ beta,
           double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
@@ -320,8 +321,6 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
           const int *__restrict__ order, int *__restrict__ fix_mark, int stamp, int *__restrict__ fix_cnt,
           int *__restrict__ fix_list)
 {
-    const int qs = blockIdx.x * (WAVE / L) + threadIdx.x / L;
-    const int i = threadIdx.x % L;
     const int k = qs % CB_CH;
     if (qs / CB_CH >= U) return;
     const int u = order[qs / CB_CH]; // longest utterances first
@@ -373,6 +372,65 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
     // the utterance goes on k_backward_fix's list once, whichever of its chunks asks first
     // (marks carry the pass's stamp: nothing is ever cleared)
     if (again && i == 0 && atomicExch(&fix_mark[u], stamp) != stamp) fix_list[atomicAdd(fix_cnt, 1)] = u;
+}
+
+template <int L, bool WANT_BETA, bool DENSE>
+__global__ void __launch_bounds__(WAVE, DENSE ? 2 : 4)
+k_combine(int N, int U, int delta, const double *__restrict__ A, const long long *__restrict__ off,
+          const double *__restrict__ alpha, const double *__restrict__ scale,
+          const double *__restrict__ wrow, const double *__restrict__ sb, double *__restrict__ beta,
+          double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
+          double *__restrict__ part_denc, double *__restrict__ sink,
+          const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
+          const int *__restrict__ order, int *__restrict__ fix_mark, int stamp, int *__restrict__ fix_cnt,
+          int *__restrict__ fix_list)
+{
+    combine_group<L, WANT_BETA, DENSE>(blockIdx.x * (WAVE / L) + threadIdx.x / L, threadIdx.x % L, N, U, delta, A, off,
+                                       alpha, scale, wrow, sb, beta, gamma, part_xi, part_dena, part_denc, sink,
+                                       lognorm, lpart, logk, order, fix_mark, stamp, fix_cnt, fix_list);
+}
+
+// A band-diagonal A (known on the host): both scans and the combine pass in ONE launch.  A block owns
+// WAVE / L utterances; wave 0 runs their forward recursion, wave 1 their backward recursion, the
+// other CB_CH - 2 waves wait at the barrier, then the block's CB_CH waves take one chunk of every
+// utterance each.  The combine pass of a block starts the moment ITS scans end: no launch boundary
+// (the separate combine launch drains, starts and ramps up: 27 -> 18 us at 1 000 utterances), its
+// operands were written by this compute unit a moment ago, and on large corpora the chip always
+// holds blocks in both phases (12 500 utterances: 0.85 -> 0.73 ms).
+template <int L, bool WANT_BETA>
+__global__ void __launch_bounds__(CB_CH *WAVE)
+k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const double *__restrict__ b,
+               const long long *__restrict__ off, double *__restrict__ alpha, double *__restrict__ scale,
+               double *__restrict__ wrow, double *__restrict__ sb, double *__restrict__ beta,
+               double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
+               double *__restrict__ part_denc, double *__restrict__ sink,
+               const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
+               const int *__restrict__ order, int *__restrict__ fix_mark, int stamp, int *__restrict__ fix_cnt,
+               int *__restrict__ fix_list)
+{
+    constexpr int gpw = WAVE / L;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), l = threadIdx.x % WAVE;
+    if (w < 2) {
+        const int slot = blockIdx.x * gpw + l / L;
+        const int i = l % L;
+        if (slot < U) {
+            const int u = order[slot];
+            const long long f0 = off[u];
+            const int T = (int)(off[u + 1] - f0);
+            if (T > 0) {
+                double *snk = wave_sink(sink);
+                if (w == 0)
+                    forward_run<L, true, false>(N, T, i, i < N, A, b + f0 * N, alpha + f0 * N, scale + f0,
+                                                (double *)nullptr, snk, N);
+                else
+                    backward_own_run<L, true>(N, T, i, i < N, A, b + f0 * N, wrow + f0 * N, sb + f0, snk);
+            }
+        }
+    }
+    __syncthreads(); // (orders the scans' global stores before the block's reads of them)
+    combine_group<L, WANT_BETA, false>(blockIdx.x * (CB_CH * gpw) + w * gpw + l / L, l % L, N, U, delta, A, off,
+                                       alpha, scale, wrow, sb, beta, gamma, part_xi, part_dena, part_denc, sink,
+                                       lognorm, lpart, logk, order, fix_mark, stamp, fix_cnt, fix_list);
 }
 
 // The utterances k_combine listed, whole, in the reference's own order of operations:

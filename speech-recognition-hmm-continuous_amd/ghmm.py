@@ -19,7 +19,7 @@ HOST_LIB = os.path.join(_HERE, "libghmm_host.so")
 OK = 0
 ERR_ARG, ERR_ALLOC, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_FORMAT = range(1, 8)
 (OPT_DELTA, OPT_ROBUST, OPT_KERNELS, OPT_TIMING, OPT_PARTIALS, OPT_CUS, OPT_REFORDER_COUNT, OPT_VEC_STATS,
- OPT_NT_POST) = range(1, 10)
+ OPT_NT_POST, OPT_FUSED_SCAN) = range(1, 11)
 (K_EMISSION, K_FORWARD, K_BACKWARD, K_MIXSTATS, K_REDUCE, K_MSTEP, K_VITERBI, K_PREPARE,
  K_COUNT) = range(9)
 (BUF_B, BUF_POST, BUF_ALPHA, BUF_BETA, BUF_SCALE, BUF_GAMMA, BUF_LOGLIK, BUF_LOGNORM) = range(8)

@@ -1182,6 +1182,39 @@ def test_class2_gaussians_both_exact_paths(G, ctx):
         corpus.close(); stats.close()
 
 
+@pytest.mark.parametrize("shape", [
+    (10, 8, 39, [300, 211, 128, 77, 1, 5, 0, 300]),     # 16-lane groups, T = 1, T < N, an empty utterance
+    (20, 2, 13, [90, 45, 19, 300, 7]),                  # 32-lane groups
+    (40, 1, 5, [120, 39, 200]),                         # 64-lane groups
+    (3, 2, 5, [17] * 70),                               # more utterances than one block's groups
+])
+def test_one_launch_recursions_equal_the_separate_launches(G, ctx, shape):
+    """k_scan_combine (both scans + the gamma / xi pass in one launch, what ghmm_estep uses on a
+    band-diagonal A) against k_scan_pair + k_combine (GHMM_OPT_FUSED_SCAN = 2): the same
+    operations in the same order, so statistics, gamma, alpha^ and log P bit for bit; and beta^
+    on demand after either."""
+    N, M, D, lens = shape
+    hm, X, lens = synth_case(G, N, M, D, lens, seed=N)
+    corpus = ctx.corpus(X, lens)
+    F = corpus.frames
+    out = {}
+    try:
+        for mode in (2, 0):
+            ctx.set_option(G.OPT_FUSED_SCAN, mode)
+            model, stats = ctx.model(hm), ctx.stats(N, M, D)
+            ctx.estep(model, corpus, stats)
+            out[mode] = (stats.download(), ctx.fetch(G.BUF_GAMMA, (F, N)), ctx.fetch(G.BUF_ALPHA, (F, N)),
+                         ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ctx.fetch(G.BUF_BETA, (F, N)))
+            model.close(); stats.close()
+        for a, b, nm in zip(out[2], out[0], ("statistics", "gamma", "alpha", "loglik", "beta")):
+            assert np.array_equal(a, b, equal_nan=True), nm
+        ref, _ = O.estep(hm, X, lens, dumps=False)
+        assert_close(out[0][0], ref, what="statistics against the oracle")
+    finally:
+        ctx.set_option(G.OPT_FUSED_SCAN, 0)
+        corpus.close()
+
+
 def test_no_utterance_of_a_fitting_model_is_taken_again(G, ctx):
     """On data the model fits (the benchmark's generator, ragged lengths) the gamma / xi pass
     must not hand anything to the reference-order kernel: the counter stays 0."""
