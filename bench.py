@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--mix", type=int, default=8)
     ap.add_argument("--dim", type=int, default=39)
     ap.add_argument("--kernels", type=int, default=0, help="0 auto, 1 vector-ALU, 2 MFMA")
+    ap.add_argument("--fused-scan", type=int, default=0,
+                    help="GHMM_OPT_FUSED_SCAN: 0 / 1 the recursions in one launch, 2 in separate launches (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the SURVEY §8(d) side measurements (decode, 64 mixtures, 2 000 states, "
@@ -108,6 +110,7 @@ def main():
     assert stream.cuda_stream != 0
     ctx = G.Context(local, stream=stream.cuda_stream)
     ctx.set_option(G.OPT_KERNELS, args.kernels)
+    ctx.set_option(G.OPT_FUSED_SCAN, args.fused_scan)
     model = ctx.model(start)
     corpus = ctx.corpus_from_device(Xd.data_ptr(), lens, D)
     backend = em.HipBackend(G, ctx, model, corpus, torch=torch)

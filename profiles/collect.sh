@@ -16,7 +16,7 @@ stats() { # $1 = name, rest = command after --
 stats bench python3 bench.py --no-extras --no-cpu-baseline --steps 40 --warmup 3
 echo "bench stats done"
 bash profiles/pmc_passes.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1
-python3 profiles/pmc_summary.py "$OUT/pmc" k_emission_sched k_mixstats_mfma k_scan_pair k_combine k_backward_fix k_reduce_all k_mstep_mfma > "$OUT/pmc_summary.txt"
+python3 profiles/pmc_summary.py "$OUT/pmc" k_emission_sched k_mixstats_mfma k_scan_combine k_scan_pair k_combine k_backward_fix k_reduce_all k_mstep_mfma > "$OUT/pmc_summary.txt"
 cp profiles/emission_traffic.json "$OUT/emission_traffic_before.json"
 python3 profiles/emission_traffic.py "$OUT/pmc" "$TAG" > "$OUT/emission_traffic.log" 2>&1 && cp profiles/emission_traffic.json "$OUT/emission_traffic.json"
 echo "pmc done"

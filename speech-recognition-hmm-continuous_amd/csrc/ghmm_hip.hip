@@ -1337,14 +1337,10 @@ static int run_scan_combine(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool *
                                             ctx->wrow, ctx->sb, ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena,
                                             ctx->part_denc, ctx->sink,
                                             ctx->robust ? ctx->lognorm : (const double *)nullptr, ctx->lpart, ctx->logk,
-                                            c->order, ctx->fix_mark, ctx->fix_stamp, ctx->fix_cnt + (ctx->fix_stamp & 1),
-                                            ctx->fix_list));
+                                            c->order, ctx->fix_cnt + (ctx->fix_stamp & 1),
+                                            ctx->fix_cnt + ((ctx->fix_stamp + 1) & 1)));
     }
     if ((rc = launch_ok("k_scan_combine"))) return rc;
-    {
-        kscope ks(ctx, GHMM_K_BACKWARD);
-        if ((rc = run_backward_fix(ctx, m, c, L, blocks, CB_CH, nullptr))) return rc;
-    }
     ctx->beta_valid = false; // beta^ on demand (ghmm_fetch)
     ctx->last_m = m;
     ctx->last_c = c;

@@ -310,8 +310,10 @@ __device__ __forceinline__ bool combine_run(int N, int T, int delta, int i, bool
 // unless j = i or i + 1, only that form is compiled (half the registers, twice the waves in
 // flight); DENSE = true decides per wave on the device like the one-pass kernels.
 // group qs = (utterance in length order, chunk), lane i of the group
+// Returns whether the utterance has to be taken again in the reference's order; with fix_mark the
+// utterance is put on k_backward_fix's list here (once, whichever of its chunks asks first).
 template <int L, bool WANT_BETA, bool DENSE>
-__device__ __forceinline__ void combine_group(int qs, int i, int N, int U, int delta, const double *__restrict__ A,
+__device__ __forceinline__ bool combine_group(int qs, int i, int N, int U, int delta, const double *__restrict__ A,
           const long long *__restrict__ off,
           const double *__restrict__ alpha, const double *__restrict__ scale,
           const double *__restrict__ wrow, const double *__restrict__ sb, double *__restrict__ beta,
@@ -322,7 +324,7 @@ __device__ __forceinline__ void combine_group(int qs, int i, int N, int U, int d
           int *__restrict__ fix_list)
 {
     const int k = qs % CB_CH;
-    if (qs / CB_CH >= U) return;
+    if (qs / CB_CH >= U) return false;
     const int u = order[qs / CB_CH]; // longest utterances first
     const int q = u * CB_CH + k;     // partial-sum slot of (utterance, chunk)
     const long long f0 = off[u];
@@ -350,7 +352,7 @@ __device__ __forceinline__ void combine_group(int qs, int i, int N, int U, int d
             part_dena[pden_at(q, i, U * CB_CH)] = 0.0;
             part_denc[pden_at(q, i, U * CB_CH)] = 0.0;
         }
-        return;
+        return false;
     }
     double *snk = wave_sink(sink);
     bool banded = true;
@@ -371,7 +373,8 @@ __device__ __forceinline__ void combine_group(int qs, int i, int N, int U, int d
                                          part_dena, part_denc, snk, U * CB_CH);
     // the utterance goes on k_backward_fix's list once, whichever of its chunks asks first
     // (marks carry the pass's stamp: nothing is ever cleared)
-    if (again && i == 0 && atomicExch(&fix_mark[u], stamp) != stamp) fix_list[atomicAdd(fix_cnt, 1)] = u;
+    if (fix_mark && again && i == 0 && atomicExch(&fix_mark[u], stamp) != stamp) fix_list[atomicAdd(fix_cnt, 1)] = u;
+    return again;
 }
 
 template <int L, bool WANT_BETA, bool DENSE>
@@ -397,6 +400,38 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
 // (the separate combine launch drains, starts and ramps up: 27 -> 18 us at 1 000 utterances), its
 // operands were written by this compute unit a moment ago, and on large corpora the chip always
 // holds blocks in both phases (12 500 utterances: 0.85 -> 0.73 ms).
+// k_backward_fix's loop body for one utterance of k_scan_combine's block (a function of its own: the
+// dense recursion's registers stay out of the kernel's main path)
+template <int L>
+__device__ __noinline__ void fix_in_block(int N, int U, int delta, int u, int i, const double *__restrict__ A,
+                                          const double *__restrict__ b, const long long *__restrict__ off,
+                                          const double *__restrict__ alpha, const double *__restrict__ scale,
+                                          double *__restrict__ beta, double *__restrict__ gamma,
+                                          double *__restrict__ part_xi, double *__restrict__ part_dena,
+                                          double *__restrict__ part_denc, double *__restrict__ snk,
+                                          int *__restrict__ fix_cnt)
+{
+    const long long f0 = off[u];
+    const int T = (int)(off[u + 1] - f0);
+    if (T <= 0) return;
+    const bool act = i < N;
+    const int S = U * CB_CH;
+    backward_run<L, false>(N, T, delta, i, act, u * CB_CH, A, b + f0 * N, alpha + f0 * N, scale + f0,
+                           (const double *)nullptr, beta + f0 * N, gamma + f0 * N, part_xi, part_dena, part_denc,
+                           snk, S);
+    if (act)
+        for (int k = 1; k < CB_CH; k++) {
+            for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(u * CB_CH + k, i, o, S)] = 0.0;
+            part_dena[pden_at(u * CB_CH + k, i, S)] = 0.0;
+            part_denc[pden_at(u * CB_CH + k, i, S)] = 0.0;
+        }
+    if (i == 0) atomicAdd(fix_cnt, 1);
+}
+
+// An utterance the combine pass wants taken again in the reference's order (see RANGE; none on data a
+// model fits) is taken again right here, by wave 0 of its block with k_backward_fix's loop, behind a
+// second barrier: the block owns every chunk of it.  fix_cnt counts them, fix_cnt_next is zeroed for
+// the next pass (as k_backward_fix does behind k_combine).
 template <int L, bool WANT_BETA>
 __global__ void __launch_bounds__(CB_CH *WAVE)
 k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const double *__restrict__ b,
@@ -405,11 +440,13 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
                double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
                double *__restrict__ part_denc, double *__restrict__ sink,
                const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
-               const int *__restrict__ order, int *__restrict__ fix_mark, int stamp, int *__restrict__ fix_cnt,
-               int *__restrict__ fix_list)
+               const int *__restrict__ order, int *__restrict__ fix_cnt, int *__restrict__ fix_cnt_next)
 {
     constexpr int gpw = WAVE / L;
+    __shared__ int fix_flag[gpw];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), l = threadIdx.x % WAVE;
+    if (threadIdx.x < gpw) fix_flag[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt_next = 0; // the counter of the next pass
     if (w < 2) {
         const int slot = blockIdx.x * gpw + l / L;
         const int i = l % L;
@@ -418,7 +455,9 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
             const long long f0 = off[u];
             const int T = (int)(off[u + 1] - f0);
             if (T > 0) {
-                double *snk = wave_sink(sink);
+                // (the scan waves' sink regions side by side: through wave_sink they would sit 8 KB
+                // apart, one per block, on a fraction of the L2 channels)
+                double *snk = sink + (size_t)((blockIdx.x * 2 + w) % SINK_WAVES) * 2 * WAVE + l;
                 if (w == 0)
                     forward_run<L, true, false>(N, T, i, i < N, A, b + f0 * N, alpha + f0 * N, scale + f0,
                                                 (double *)nullptr, snk, N);
@@ -428,9 +467,17 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
         }
     }
     __syncthreads(); // (orders the scans' global stores before the block's reads of them)
-    combine_group<L, WANT_BETA, false>(blockIdx.x * (CB_CH * gpw) + w * gpw + l / L, l % L, N, U, delta, A, off,
+    const int gid = w * gpw + l / L; // (utterance of the block, chunk) = (gid / CB_CH, gid % CB_CH)
+    const bool again = combine_group<L, WANT_BETA, false>(blockIdx.x * (CB_CH * gpw) + gid, l % L, N, U, delta, A, off,
                                        alpha, scale, wrow, sb, beta, gamma, part_xi, part_dena, part_denc, sink,
-                                       lognorm, lpart, logk, order, fix_mark, stamp, fix_cnt, fix_list);
+                                       lognorm, lpart, logk, order, (int *)nullptr, 0, (int *)nullptr, (int *)nullptr);
+    if (again && (l % L) == 0) fix_flag[gid / CB_CH] = 1;
+    __syncthreads();
+    if (w != 0) return;
+    const int g = l / L, slot = blockIdx.x * gpw + g;
+    if (slot >= U || !fix_flag[g]) return;
+    fix_in_block<L>(N, U, delta, order[slot], l % L, A, b, off, alpha, scale, beta, gamma, part_xi, part_dena, part_denc,
+                    wave_sink(sink), fix_cnt);
 }
 
 // The utterances k_combine listed, whole, in the reference's own order of operations:
