@@ -235,7 +235,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_ms": {k: (round(v, 5) if v else None) for k, v in kavg.items()},
             "kernel_ms_source": "second, instrumented pass of the same K steps (two HIP events per launch; "
-                                "it runs a few % slower than the timed pass, so the sum exceeds ms_per_step)",
+                                "it runs a few % slower than the timed pass, so the sum exceeds ms_per_step); "
+                                "'forward' = k_scan_combine when 'backward' is null: both scans and the gamma / xi "
+                                "pass of the E-step in one launch",
             "clock_spinup_steps": max(0, args.spinup),
             # the same W + K steps BEFORE the spin-up, on a GPU coming out of idle
             "ms_per_step_cold": round(1e3 * elapsed_cold / args.steps, 4),

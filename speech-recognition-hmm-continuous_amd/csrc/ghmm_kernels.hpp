@@ -301,7 +301,10 @@ __device__ inline double *wave_sink(double *sink)
 }
 
 constexpr int PF = 8;   // frames of b / alpha prefetched ahead of the serial recursion
-constexpr int PFF = 16; // the same for the forward pass (one operand stream, more room)
+#ifndef GHMM_PFF
+#define GHMM_PFF 16 // (measurement builds override it: profiles/tools/lab.sh)
+#endif
+constexpr int PFF = GHMM_PFF; // the same for the forward pass (one operand stream, more room)
 // frames of padding the host keeps in front of and behind the emission densities b[F][N]: the
 // scans' operand cursors run up to 2 PFF frames past either end of an utterance
 constexpr int B_PAD_FRAMES = 2 * PFF;
