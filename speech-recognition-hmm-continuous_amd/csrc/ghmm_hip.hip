@@ -1247,7 +1247,7 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
         if ((rc = wide_band_flag(ctx, m, m->A, 0.0))) return rc;
         kscope ks(ctx, GHMM_K_BACKWARD);
         hipLaunchKernelGGL(k_backward_wide, dim3((unsigned)c->U), dim3(WAVE),
-                           (size_t)(4 + MAX_DELTA + 1) * m->N * sizeof(double), ctx->stream, m->N, c->U,
+                           (size_t)(6 + MAX_DELTA + 1) * m->N * sizeof(double), ctx->stream, m->N, c->U,
                            (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta, ctx->gamma,
                            ctx->part_xi, ctx->part_dena, ctx->part_denc, c->order, ctx->wide_flag);
         ctx->beta_valid = true;

@@ -15,7 +15,7 @@
 
 namespace ghmm {
 
-constexpr int WIDE_MAX = 512; // states; LDS of the backward pass: 12 N doubles
+constexpr int WIDE_MAX = 512; // states; LDS of the backward pass: (6 + MAX_DELTA + 1) N doubles = 56 KB
 
 // flag[0] = 1 when some entry outside {j = i, j = i + 1} differs from `zero` (0 for A, -inf for log A)
 __global__ void __launch_bounds__(256)
@@ -104,7 +104,7 @@ k_backward_wide(int N, int U, int delta, const double *__restrict__ A, const dou
                 double *__restrict__ part_denc, const int *__restrict__ order,
                 const int *__restrict__ offband)
 {
-    extern __shared__ double lds[]; // be[N] | w[N] | dena[N] | denc[N] | xi[MAX_DELTA + 1][N]
+    extern __shared__ double lds[]; // be[N] | w[N] | dena[N] | denc[N] | aself[N] | anext[N] | xi[MAX_DELTA + 1][N]
     const int l = threadIdx.x;
     const int u = order[blockIdx.x];
     const long long f0 = off[u];
@@ -117,7 +117,12 @@ k_backward_wide(int N, int U, int delta, const double *__restrict__ A, const dou
         }
         return;
     }
-    double *be = lds, *w = lds + N, *dena = lds + 2 * N, *denc = lds + 3 * N, *xi = lds + 4 * N;
+    double *be = lds, *w = lds + N, *dena = lds + 2 * N, *denc = lds + 3 * N, *aself = lds + 4 * N,
+           *anext = lds + 5 * N, *xi = lds + 6 * N;
+    for (int i = l; i < N; i += WAVE) {
+        aself[i] = A[(size_t)i * N + i];
+        anext[i] = i + 1 < N ? A[(size_t)i * N + i + 1] : 0.0;
+    }
     const double *bu = b + f0 * N, *au = alpha + f0 * N, *su = scale + f0;
     double *beu = beta + f0 * N, *gu = gamma + f0 * N;
     bool dense = offband[0] != 0;
@@ -144,7 +149,7 @@ k_backward_wide(int N, int U, int delta, const double *__restrict__ A, const dou
             for (int i = l; i < N; i += WAVE) {
                 double aux;
                 if (!dense) {
-                    aux = A[(size_t)i * N + i] * w[i] + (i + 1 < N ? A[(size_t)i * N + i + 1] * w[i + 1] : 0.0);
+                    aux = aself[i] * w[i] + (i + 1 < N ? anext[i] * w[i + 1] : 0.0);
                 } else {
                     aux = 0.0;
                     for (int j = 0; j < N; j++) aux += A[(size_t)i * N + j] * w[j];
