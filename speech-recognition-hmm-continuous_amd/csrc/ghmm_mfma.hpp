@@ -1313,6 +1313,14 @@ __device__ inline void divmod_small(int e, int d, float rd, int &q, int &r)
     }
 }
 
+// e / d for small non-negative e (see divmod_small)
+__device__ inline int div_small(int e, int d, float rd)
+{
+    int q, r;
+    divmod_small(e, d, rd, q, r);
+    return q;
+}
+
 constexpr int MSM_WAVES = 4;
 
 // smask[stage] bit i = gamma_t(i) != 0 for some frame t of the 16-frame stage (N <= 32).  One
@@ -1358,16 +1366,20 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                 const unsigned *__restrict__ smask = nullptr)
 {
     extern __shared__ double lds[]; // fold: [CT*NE*4][64]; STAGED: per-wave frame stages
+    const unsigned long long t_entry = (GHMM_LAB & 8192) ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_loop0 = 0, t_loop1 = 0;
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index, in a scalar register
     const int G = N * M, ES = NE * 16;
     const int c0 = STAGED ? gmin / 16 : blockIdx.y * CT; // staged: one launch per chunk
     int gmA[CT], stA[CT];
+    const float rMp = 1.0f / (float)Mp, rM = 1.0f / (float)M, rN = 1.0f / (float)N;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
         const int gp = (c0 + c) * 16 + j;
         gmA[c] = (c0 + c < NT) ? gmap[gp] : -1;
-        stA[c] = gp / Mp;
+        stA[c] = div_small(gp, Mp, rMp); // (float reciprocal + correction: the integer divisions of
+                                         // this set-up were a third of the kernel's first 13 000 cycles)
     }
     // per-lane feature constants of the direct (non-staged) operand path; rebuilt where
     // they are used so that they do not stay live across the staged main loop
@@ -1398,7 +1410,10 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
     const long long wi = (long long)blockIdx.x * MSM_WAVES + w;
     constexpr int UNIT = STAGED ? 16 : 4;
     const long long steps = F / UNIT;
-    const long long s0 = steps * wi / nwaves, s1 = steps * (wi + 1) / nwaves;
+    // floor(steps wi / nwaves) through one f64 division each: exact while steps wi < 2^52 (the two
+    // 64-bit integer divisions were ~500 scalar instructions of a lone wave's set-up)
+    const double rnw = (double)nwaves;
+    const long long s0 = (long long)floor((double)(steps * wi) / rnw), s1 = (long long)floor((double)(steps * (wi + 1)) / rnw);
 
     int gmC[CT];
     double mk[CT]; // 1 for a real Gaussian, 0 for padding: masks by multiplication, so
@@ -1453,6 +1468,22 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         unsigned pst[NPL];                     // state of the piece's two Gaussians (M even)
         unsigned offpB[NPL], pbit[NPL], pcxB[NXL]; // byte offsets inside a stage, state bit, frame piece bytes
         unsigned gb0[NGL], gb1[NGL];           // state bits of the two gammas of a piece
+        // the first two stages' gammas are asked for before anything else: the tables below are
+        // built under their trip to memory (the kernel's first 13 000 cycles were 12 % of it)
+#pragma unroll
+        for (int u = 0; u < NGL; u++) {
+            const int pc = l + 64 * u;
+            pcg[u] = (unsigned)(pc < ngp ? pc : ngp - 1);
+        }
+        if (!MASKED && s0 < s1) {
+            const v2d *g0 = (const v2d *)(gamma + uniform64(s0 * 16 * N));
+            const v2d *g1 = (const v2d *)(gamma + uniform64((s0 + 1 < s1 ? s0 + 1 : s0) * 16 * N));
+#pragma unroll
+            for (int u = 0; u < NGL; u++) {
+                rg[u] = g0[pcg[u]];
+                rgn[u] = g1[pcg[u]];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NPL; u++) {
             int pc = l + 64 * u;
@@ -1461,7 +1492,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             int row, c2;
             divmod_small(pc, ppr, rppr, row, c2);
             offp[u] = (unsigned)(row * G + gmin + 2 * c2);
-            pst[u] = (unsigned)((gmin + 2 * c2) / M);
+            pst[u] = (unsigned)div_small(gmin + 2 * c2, M, rM);
             offpB[u] = (offp[u] - (unsigned)gmin) * 8u;
             pbit[u] = 1u << pst[u];
         }
@@ -1469,15 +1500,18 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         for (int u = 0; u < NGL; u++) {
             const int pc = l + 64 * u;
             pcg[u] = (unsigned)(pc < ngp ? pc : ngp - 1);
-            gb0[u] = 1u << ((2 * pcg[u]) % (unsigned)N);
-            gb1[u] = 1u << ((2 * pcg[u] + 1) % (unsigned)N);
+            int q0, r0, q1, r1;
+            divmod_small((int)(2 * pcg[u]), N, rN, q0, r0);
+            divmod_small((int)(2 * pcg[u] + 1), N, rN, q1, r1);
+            gb0[u] = 1u << r0;
+            gb1[u] = 1u << r1;
         }
         // states covered by Gaussian tile c of this chunk
         unsigned tm[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) {
             const int g_lo = (c0 + c) * 16, g_hi = g_lo + 15;
-            const int s_lo = g_lo / Mp, s_hi = g_hi / Mp < N ? g_hi / Mp : N - 1;
+            const int s_lo = div_small(g_lo, Mp, rMp), s_hq = div_small(g_hi, Mp, rMp), s_hi = s_hq < N ? s_hq : N - 1;
             tm[c] = (c0 + c < NT && s_lo < N) ? ((2u << s_hi) - 1u) & ~((1u << s_lo) - 1u) : 0u;
         }
         // bit i = some frame of the stage whose gammas sit in `q` has gamma(state i) != 0
@@ -1569,6 +1603,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             mval = 0;
             return s1;
         };
+        const unsigned long long t_tab = (GHMM_LAB & 8192) ? __builtin_amdgcn_s_memtime() : 0ull;
         unsigned smask_cur = 0;
         long long cur = s0; // MASKED: the stage being staged
         if (MASKED) {
@@ -1578,15 +1613,22 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                 fetch(cur, smask_cur);
             }
         } else if (s0 < s1) {
-            fetch_gamma(s0, rg);
-            fetch_gamma(s0 + 1 < s1 ? s0 + 1 : s0, rgn);
-            smask_cur = state_mask(rg);
+            smask_cur = state_mask(rg); // (rg, rgn: asked for at the top)
             fetch(s0, smask_cur);
         }
+        const unsigned long long t_fet = (GHMM_LAB & 8192) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (l < DP) ol[l] = og_l;
         if (l + WAVE < DP) ol[l + WAVE] = og_h;
-        for (int r = 0; r < 16; r++)               // constant columns: the 1 and the zeros
-            for (int col = l; col < XS; col += WAVE) fx[r * XS + col] = col == D ? 1.0 : 0.0;
+        {   // constant columns only (the stage writer rewrites the others): the 1 at D, zeros in
+            // D+1 .. DP-1 and DP+D .. XS-1 — two columns at D = 39, one LDS write per lane for all
+            // 16 rows (filling the whole 16 x XS stage took 3 000 cycles of the kernel's set-up)
+            const int nlo = DP - D, ncc = XS - 2 * D;
+            for (int k = l; k < 16 * ncc; k += WAVE) {
+                const int r = k / ncc, cc = k - r * ncc;
+                const int col = cc < nlo ? D + cc : DP + D + (cc - nlo);
+                fx[r * XS + col] = col == D ? 1.0 : 0.0;
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // the offsets of this lane's frame pieces, fixed for the whole kernel: in registers (the
         // stage writer of a lone wave pays ~10 cycles per instruction, and ten LDS reads per stage
@@ -1724,9 +1766,12 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         if (GHMM_LAB & 8192) {
             const unsigned long long tend = __builtin_amdgcn_s_memtime();
             tw3 = (tend - tbeg) - tw0 - tw1 - tw2;
-            if (l == 0 && (blockIdx.x % 64) == 3 && gmin == 0)
+            if (l == 0 && (blockIdx.x % 64) == 3 && gmin == 0 && !(GHMM_LAB & 16384))
                 printf("mixstats block %d wave %d: %llu stages, cycles total %llu: load wait %llu, stage writer %llu, fetch issue %llu, k-steps+rest %llu\n",
                        (int)blockIdx.x, w, tst, tend - tbeg, tw0, tw1, tw2, tw3);
+            t_loop0 = tbeg; t_loop1 = tend;
+            if (l == 0 && (blockIdx.x % 64) == 3 && gmin == 0 && w == 0)
+                printf("mixstats block %d: entry -> tables done %llu, -> first fetch issued %llu, -> loop %llu\n", (int)blockIdx.x, t_tab - t_entry, t_fet - t_tab, tbeg - t_fet);
         }
         __syncthreads(); // the stages alias the fold buffer below
     } else
@@ -1826,6 +1871,12 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             const int gp = (c0 + c) * 16 + kq + 4 * r;
             if (c0 + c < NT) part[((size_t)blockIdx.x * NT * 16 + gp) * ES + 16 * n + j] = v;
         }
+    }
+    if (GHMM_LAB & 8192) {
+        const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
+        if (l == 0 && (blockIdx.x % 64) == 3 && gmin == 0)
+            printf("mixstats block %d wave %d: cycles before the stage loop %llu, behind it (fold + partial) %llu\n",
+                   (int)blockIdx.x, w, t_loop0 - t_entry, t_exit - t_loop1);
     }
 }
 
