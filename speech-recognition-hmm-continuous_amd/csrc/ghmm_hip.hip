@@ -1381,8 +1381,8 @@ template <int CT, int NE>
 static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int P, int chunks)
 {
     const bool ntl = nt_posteriors(ctx, m, c); // (single-chunk launches only: small models)
-    // fold buffer: four waves x half of the tiles (ghmm_mfma.hpp, end of k_mixstats_mfma)
-    const size_t fold = (size_t)MSM_WAVES * ((CT * NE + 1) / 2) * 4 * 64 * sizeof(double);
+    // fold buffer: three of the four register rows of every tile, four waves (ghmm_mfma.hpp, end of k_mixstats_mfma)
+    const size_t fold = (size_t)CT * NE * 4 * 3 * 64 * sizeof(double);
     // staged variant: every chunk of CT tiles must map to an even-aligned, even-length run of
     // real Gaussians (true when no mixture padding: Mp == M, M even) and N <= 32 (two 16-byte
     // gamma pieces per lane and stage up to 16 states, four beyond)

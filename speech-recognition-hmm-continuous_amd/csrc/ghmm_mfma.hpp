@@ -20,6 +20,7 @@
 // Fragment maps (cdna_hip_programming.md §3): lane l, A[i = l&15][k = l>>4],
 // B[k = l>>4][j = l&15], C/D reg r -> row (l>>4) + 4r, col l&15.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "ghmm_kernels.hpp"
@@ -1365,7 +1366,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                 const double *__restrict__ oglob, double *__restrict__ part,
                 const unsigned *__restrict__ smask = nullptr)
 {
-    extern __shared__ double lds[]; // fold: [CT*NE*4][64]; STAGED: per-wave frame stages
+    extern __shared__ double lds[]; // fold: [CT*NE][4 rows][3 writers][64]; STAGED: per-wave frame stages
     const unsigned long long t_entry = (GHMM_LAB & 8192) ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_loop0 = 0, t_loop1 = 0;
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
@@ -1773,7 +1774,6 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             if (l == 0 && (blockIdx.x % 64) == 3 && gmin == 0 && w == 0)
                 printf("mixstats block %d: entry -> tables done %llu, -> first fetch issued %llu, -> loop %llu\n", (int)blockIdx.x, t_tab - t_entry, t_fet - t_tab, tbeg - t_fet);
         }
-        __syncthreads(); // the stages alias the fold buffer below
     } else
     // Software pipeline over k-steps: operands are fetched MSM_PD k-steps ahead.  Addresses
     // are a wave-uniform base (scalar registers) plus a 32-bit per-lane element offset that
@@ -1843,35 +1843,44 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             }
         }
     }
-    // Fold the block's waves in wave order and write the block's partial, all four waves at
-    // work: in two rounds of half the tiles, every wave parks its tiles in LDS, then each wave
-    // adds up (wave 0 + wave 1 + wave 2 + wave 3, in that order) a quarter of the round's
-    // tile rows and stores them.
-    constexpr int TILES = CT * NE, TPR = (TILES + 1) / 2; // tiles per round
+    // Fold the block's waves in wave order and write the block's partial, all four waves at work,
+    // in ONE round: wave W keeps register row W of every tile and parks its other three rows in LDS
+    // (3/4 of 4 waves' tiles: exactly 150 KB at 25 tiles); behind the barrier it adds up rows W of
+    // wave 0 + wave 1 + wave 2 + wave 3, in that order (its own from registers), and stores them.
+    // (Two rounds of half the tiles with every row parked: 104 + 104 LDS accesses and 4 barriers per
+    // wave instead of 75 + 75 and 2.)
+    __syncthreads(); // the stages alias the fold buffer
+    auto fold = [&](auto wc) {
+        constexpr int W = decltype(wc)::value;
 #pragma unroll
-    for (int rnd = 0; rnd < 2; rnd++) {
+        for (int c = 0; c < CT; c++)
+#pragma unroll
+            for (int n = 0; n < NE; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (r != W) // slot (tile, row r, rank of the writer among the three waves != r)
+                        lds[((size_t)((c * NE + n) * 4 + r) * 3 + (W < r ? W : W - 1)) * 64 + l] = acc[c][n][r];
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < CT; c++)
 #pragma unroll
             for (int n = 0; n < NE; n++) {
-                const int tl = c * NE + n - rnd * TPR; // tile index inside this round
-                if (tl >= 0 && tl < TPR) {
+                double v = 0.0;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) lds[((size_t)(w * TPR + tl) * 4 + r) * 64 + l] = acc[c][n][r];
+                for (int ww = 0; ww < MSM_WAVES; ww++) {
+                    const double x = ww == W ? acc[c][n][W]
+                                             : lds[((size_t)((c * NE + n) * 4 + W) * 3 + (ww < W ? ww : ww - 1)) * 64 + l];
+                    v = ww == 0 ? x : v + x;
                 }
+                const int gp = (c0 + c) * 16 + kq + 4 * W;
+                if (c0 + c < NT) part[((size_t)blockIdx.x * NT * 16 + gp) * ES + 16 * n + j] = v;
             }
-        __syncthreads();
-        const int nt = (TILES - rnd * TPR) < TPR ? (TILES - rnd * TPR) : TPR;
-        for (int q = w; q < nt * 4; q += MSM_WAVES) { // q = (tile, register row)
-            const int tl = q >> 2, r = q & 3, t = tl + rnd * TPR, c = t / NE, n = t - c * NE;
-            double v = lds[((size_t)(0 * TPR + tl) * 4 + r) * 64 + l];
-#pragma unroll
-            for (int ww = 1; ww < MSM_WAVES; ww++) v += lds[((size_t)(ww * TPR + tl) * 4 + r) * 64 + l];
-            const int gp = (c0 + c) * 16 + kq + 4 * r;
-            if (c0 + c < NT) part[((size_t)blockIdx.x * NT * 16 + gp) * ES + 16 * n + j] = v;
-        }
-    }
+    };
+    // (w is wave-uniform: one of four copies of the code runs, each with constant register indices)
+    if (w == 0) fold(std::integral_constant<int, 0>{});
+    else if (w == 1) fold(std::integral_constant<int, 1>{});
+    else if (w == 2) fold(std::integral_constant<int, 2>{});
+    else fold(std::integral_constant<int, 3>{});
     if (GHMM_LAB & 8192) {
         const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
         if (l == 0 && (blockIdx.x % 64) == 3 && gmin == 0)
