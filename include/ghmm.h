@@ -118,8 +118,9 @@ int ghmm_ctx_get_option(ghmm_ctx *ctx, int option, int64_t *value);
 /* kernel ids for ghmm_ctx_kernel_time() */
 enum {
     GHMM_K_EMISSION = 0,
-    GHMM_K_FORWARD = 1,
-    GHMM_K_BACKWARD = 2,
+    GHMM_K_FORWARD = 1,  /* forward recursion; inside ghmm_estep on a band-diagonal A the one launch that
+                          * holds both recursions and the gamma / xi pass (then GHMM_K_BACKWARD counts nothing) */
+    GHMM_K_BACKWARD = 2, /* backward recursion's share: gamma / xi pass and the fix-up launch */
     GHMM_K_MIXSTATS = 3,
     GHMM_K_REDUCE = 4,
     GHMM_K_MSTEP = 5,

@@ -8,7 +8,8 @@
 //     v_t       = A W_t,   beta~_t = v_t 2^(e_t),  e_t = BT_K - exponent(sum_i v_t(i))   (2^(e_t) kept)
 //     beta~_{T-1} = e_{N-1}                                      (final-state constraint, TF:1484-1490)
 // so that it needs nothing from the forward pass and runs beside it in the same launch
-// (k_scan_pair, blockIdx.y = direction).  beta~_t is the reference's beta^_t up to a factor
+// (k_scan_pair, blockIdx.y = direction; k_scan_combine, waves 0 and 1 of a block, with the combine
+// pass below behind a barrier in the same launch).  beta~_t is the reference's beta^_t up to a factor
 // rho_t, and the reference's own scaling fixes that factor:
 //     sum_i alpha^_t(i) beta^_t(i) = c_t kappa,  kappa = alpha^_{T-1}(N-1)      (induction on TF:1507)
 //     =>  rho_t = c_t kappa / D_t,   D_t = sum_i alpha^_t(i) beta~_t(i)
