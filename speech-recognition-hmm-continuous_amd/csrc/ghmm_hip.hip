@@ -1245,9 +1245,10 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
     if ((rc = fb_lanes(m, &L))) return rc;
     if (L == 0) {
         if ((rc = wide_band_flag(ctx, m, m->A, 0.0))) return rc;
+        if ((rc = lds_attr(ctx, (const void *)k_backward_wide))) return rc; // (64 KB at 512 states)
         kscope ks(ctx, GHMM_K_BACKWARD);
         hipLaunchKernelGGL(k_backward_wide, dim3((unsigned)c->U), dim3(WAVE),
-                           (size_t)(6 + MAX_DELTA + 1) * m->N * sizeof(double), ctx->stream, m->N, c->U,
+                           (size_t)(8 + MAX_DELTA + 1) * m->N * sizeof(double), ctx->stream, m->N, c->U,
                            (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->beta, ctx->gamma,
                            ctx->part_xi, ctx->part_dena, ctx->part_denc, c->order, ctx->wide_flag);
         ctx->beta_valid = true;

@@ -15,7 +15,7 @@
 
 namespace ghmm {
 
-constexpr int WIDE_MAX = 512; // states; LDS of the backward pass: (6 + MAX_DELTA + 1) N doubles = 56 KB
+constexpr int WIDE_MAX = 512; // states; LDS of the backward pass: (8 + MAX_DELTA + 1) N doubles = 64 KB (raised limit)
 
 // flag[0] = 1 when some entry outside {j = i, j = i + 1} differs from `zero` (0 for A, -inf for log A)
 __global__ void __launch_bounds__(256)
@@ -104,7 +104,7 @@ k_backward_wide(int N, int U, int delta, const double *__restrict__ A, const dou
                 double *__restrict__ part_denc, const int *__restrict__ order,
                 const int *__restrict__ offband)
 {
-    extern __shared__ double lds[]; // be[N] | w[N] | dena[N] | denc[N] | aself[N] | anext[N] | xi[MAX_DELTA + 1][N]
+    extern __shared__ double lds[]; // be[N] | w[N] | dena[N] | denc[N] | aself[N] | anext[N] | xi[MAX_DELTA + 1][N] | bo[N] | bn[N]
     const int l = threadIdx.x;
     const int u = order[blockIdx.x];
     const long long f0 = off[u];
@@ -118,7 +118,7 @@ k_backward_wide(int N, int U, int delta, const double *__restrict__ A, const dou
         return;
     }
     double *be = lds, *w = lds + N, *dena = lds + 2 * N, *denc = lds + 3 * N, *aself = lds + 4 * N,
-           *anext = lds + 5 * N, *xi = lds + 6 * N;
+           *anext = lds + 5 * N, *xi = lds + 6 * N, *bo = xi + (size_t)(MAX_DELTA + 1) * N, *bn = bo + N;
     for (int i = l; i < N; i += WAVE) {
         aself[i] = A[(size_t)i * N + i];
         anext[i] = i + 1 < N ? A[(size_t)i * N + i + 1] : 0.0;
@@ -143,16 +143,22 @@ k_backward_wide(int N, int U, int delta, const double *__restrict__ A, const dou
         }
         __syncthreads();
         for (int t = T - 2; t >= 0; t--) {
-            for (int i = l; i < N; i += WAVE) w[i] = be[i] * bu[(size_t)(t + 1) * N + i];
+            for (int i = l; i < N; i += WAVE) {
+                const double bj = bu[(size_t)(t + 1) * N + i];
+                bo[i] = be[i]; // beta^_{t+1} and b(t+1) apart: the recursion multiplies them in the
+                bn[i] = bj;    // reference's association, (beta^ a) b (TF:1505)
+                w[i] = be[i] * bj;
+            }
             __syncthreads();
             const double c = su[t], sv = 1.0 / c;
             for (int i = l; i < N; i += WAVE) {
                 double aux;
                 if (!dense) {
-                    aux = aself[i] * w[i] + (i + 1 < N ? anext[i] * w[i + 1] : 0.0);
+                    aux = (bo[i] * aself[i]) * bn[i];
+                    if (i + 1 < N) aux += (bo[i + 1] * anext[i]) * bn[i + 1];
                 } else {
                     aux = 0.0;
-                    for (int j = 0; j < N; j++) aux += A[(size_t)i * N + j] * w[j];
+                    for (int j = 0; j < N; j++) aux += (bo[j] * A[(size_t)i * N + j]) * bn[j];
                 }
                 const double al = au[(size_t)t * N + i];
                 for (int o = 0; o <= delta; o++)

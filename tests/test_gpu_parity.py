@@ -1736,3 +1736,19 @@ def test_more_models_than_flag_slots(G, ctx):
             assert_close(a, b, rtol=1e-7, what="model")
     for o in models + [corpus, stats]:
         o.close()
+
+
+def test_the_widest_model_the_recursions_take(G, ctx):
+    """512 states (ghmm_wide.hpp's limit: 64 KB of LDS in the backward pass) against the oracle."""
+    hm, X, lens = synth_case(G, 512, 1, 3, [530, 40], seed=77)
+    ref, _ = O.estep(hm, X, lens, dumps=False)
+    model, corpus = ctx.model(hm), ctx.corpus(X, lens)
+    stats = ctx.stats(512, 1, 3)
+    try:
+        ctx.estep(model, corpus, stats)
+        got = stats.download()
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert_close(got, ref, what="statistics at 512 states")
+    finally:
+        for o_ in (model, corpus, stats):
+            o_.close()
