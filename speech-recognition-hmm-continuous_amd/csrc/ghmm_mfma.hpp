@@ -1325,22 +1325,58 @@ __device__ inline int div_small(int e, int d, float rd)
 constexpr int MSM_WAVES = 4;
 
 // smask[stage] bit i = gamma_t(i) != 0 for some frame t of the 16-frame stage (N <= 32).  One
-// wave per 4 stages, lane = frame.
+// wave per 4 stages = 64 frames = 64 N consecutive doubles, read coalesced (lane l takes elements
+// l, l + 64, ...: N independent loads in flight; one frame per lane with a ballot per state ran N
+// dependent round trips per wave: 76 us at 20 states x 300 000 frames, now a pass over gamma).
 __global__ void __launch_bounds__(WAVE)
 k_stage_masks(int N, long long F, const double *__restrict__ gamma, unsigned *__restrict__ smask)
 {
     const int l = threadIdx.x;
-    const long long f = ((long long)blockIdx.x * WAVE) + l;
-    const bool ok = f < F;
-    const double *g = gamma + (ok ? f : F - 1) * N;
+    const long long f0 = (long long)blockIdx.x * WAVE;          // first frame of the wave
+    const long long nel = (F - f0 < WAVE ? F - f0 : WAVE) * N;  // elements of its frames
+    const double *g = gamma + f0 * N;
+    // element e = l + 64 k: frame e / N, state e % N, advanced without divisions
+    const int dq = WAVE / N, dr = WAVE % N;
+    int fr = l / N, st = l % N;
     unsigned m[4] = {0u, 0u, 0u, 0u};
-    for (int i = 0; i < N; i++) {
-        const unsigned long long nz = __ballot(ok && g[i] != 0.0);
+    for (long long e0 = 0; e0 < nel; e0 += 8 * WAVE) {
+        double v[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) m[q] |= ((nz >> (16 * q)) & 0xffffull) != 0ull ? (1u << i) : 0u;
+        for (int k = 0; k < 8; k++) {
+            const long long e = e0 + k * WAVE + l;
+            v[k] = g[e < nel ? e : nel - 1]; // clamped, never predicated
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool in = e0 + k * WAVE + l < nel;
+            const unsigned bit = (in && v[k] != 0.0) ? (1u << st) : 0u;
+            const int q = fr >> 4;
+            m[0] |= q == 0 ? bit : 0u;
+            m[1] |= q == 1 ? bit : 0u;
+            m[2] |= q == 2 ? bit : 0u;
+            m[3] |= q == 3 ? bit : 0u;
+            fr += dq;
+            st += dr;
+            if (st >= N) {
+                st -= N;
+                fr++;
+            }
+        }
     }
-    const long long st = (long long)blockIdx.x * 4 + l;
-    if (l < 4 && st * 16 < F) smask[st] = l == 0 ? m[0] : (l == 1 ? m[1] : (l == 2 ? m[2] : m[3]));
+    // OR over the wave's lanes (as in k_mixstats_mfma's state_mask), the totals in lane 63
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int v = (int)m[q];
+        v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); // row_half_mirror
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true); // row_mirror
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast15 into rows 1 and 3
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast31 into rows 2 and 3
+        m[q] = (unsigned)__builtin_amdgcn_readlane(v, 63);
+    }
+    const long long sg = (long long)blockIdx.x * 4 + l;
+    if (l < 4 && sg * 16 < F) smask[sg] = l == 0 ? m[0] : (l == 1 ? m[1] : (l == 2 ? m[2] : m[3]));
 }
 constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
