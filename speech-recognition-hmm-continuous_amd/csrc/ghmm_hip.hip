@@ -1321,8 +1321,7 @@ static int run_scan_combine(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool *
     if (c->U == 0 || !use_pair(ctx, m) || ctx->fused_scan == 2) return GHMM_OK;
     if ((rc = fb_lanes(m, &L))) return rc;
     const bool band2 = m->banded && ctx->delta <= 1;
-    const int gpw = WAVE / L;
-    const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
+    const unsigned blocks = (unsigned)((c->U + SC_UPB - 1) / SC_UPB);
     if (!band2) return GHMM_OK;
     ctx->own_bwd_done = true;
     ctx->loglik_pieces = true; // the combine phase takes the logs of log P

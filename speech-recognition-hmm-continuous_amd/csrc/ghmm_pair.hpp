@@ -38,6 +38,7 @@ namespace ghmm {
 #define GHMM_CB_CH 8 // (measurement builds override it: profiles/tools/lab.sh)
 #endif
 constexpr int CB_CH = GHMM_CB_CH; // chunks of an utterance handled by different groups of k_combine
+constexpr int SC_UPB = 4; // utterances per block of k_scan_combine
 constexpr int CB_PF = 4; // frames of operands read ahead in k_combine (x 2 register sets x 4 operands)
 // rows of beta~ are scaled to a sum in [2^BT_K, 2^(BT_K+1)): W = b beta~ stays finite for densities
 // up to 1e100 (a 39-d Gaussian at the 1e-5 variance floor peaks at 1e82) and keeps 512 decades
@@ -395,10 +396,10 @@ k_combine(int N, int U, int delta, const double *__restrict__ A, const long long
 }
 
 // A band-diagonal A (known on the host): both scans and the combine pass in ONE launch.  A block owns
-// WAVE / L utterances; wave 0 runs their forward recursion, wave 1 their backward recursion, the
-// other CB_CH - 2 waves wait at the barrier, then the block's CB_CH waves take one chunk of every
-// utterance each.  The combine pass of a block starts the moment ITS scans end: no launch boundary
-// (the separate combine launch drains, starts and ramps up: 27 -> 18 us at 1 000 utterances), its
+// four utterances; at 16-lane groups wave 0 runs their forward recursion, wave 1 their backward
+// recursion (wider groups: more scan waves), the other waves wait at the barrier, then the block's
+// CB_CH waves take one chunk of every utterance each.  The combine pass of a block starts the moment
+// ITS scans end: no launch boundary (the separate combine launch drains, starts and ramps up: 27 -> 18 us at 1 000 utterances), its
 // operands were written by this compute unit a moment ago, and on large corpora the chip always
 // holds blocks in both phases (12 500 utterances: 0.85 -> 0.73 ms).
 // k_backward_fix's loop body for one utterance of k_scan_combine's block (a function of its own: the
@@ -443,13 +444,17 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
                const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
                const int *__restrict__ order, int *__restrict__ fix_cnt, int *__restrict__ fix_cnt_next)
 {
-    constexpr int gpw = WAVE / L;
-    __shared__ int fix_flag[gpw];
+    // SC_UPB utterances per block whatever the group width: 2 (L = 16), 4 (32) or 8 (64) scan
+    // waves — forward and backward of WAVE / L utterances each — and the block's SC_UPB x CB_CH
+    // combine groups in 1, 2 or 4 passes of its eight waves.  (With WAVE / L utterances per block a
+    // 20-state model made 500 blocks of 1 000 utterances, two rounds over the compute units.)
+    constexpr int gpw = WAVE / L, NSW = 2 * (SC_UPB / gpw), PASSES = SC_UPB * CB_CH / (CB_CH * gpw);
+    __shared__ int fix_flag[SC_UPB];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), l = threadIdx.x % WAVE;
-    if (threadIdx.x < gpw) fix_flag[threadIdx.x] = 0;
+    if (threadIdx.x < SC_UPB) fix_flag[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt_next = 0; // the counter of the next pass
-    if (w < 2) {
-        const int slot = blockIdx.x * gpw + l / L;
+    if (w < NSW) {
+        const int slot = blockIdx.x * SC_UPB + (w >> 1) * gpw + l / L;
         const int i = l % L;
         if (slot < U) {
             const int u = order[slot];
@@ -458,8 +463,8 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
             if (T > 0) {
                 // (the scan waves' sink regions side by side: through wave_sink they would sit 8 KB
                 // apart, one per block, on a fraction of the L2 channels)
-                double *snk = sink + (size_t)((blockIdx.x * 2 + w) % SINK_WAVES) * 2 * WAVE + l;
-                if (w == 0)
+                double *snk = sink + (size_t)((blockIdx.x * NSW + w) % SINK_WAVES) * 2 * WAVE + l;
+                if ((w & 1) == 0)
                     forward_run<L, true, false>(N, T, i, i < N, A, b + f0 * N, alpha + f0 * N, scale + f0,
                                                 (double *)nullptr, snk, N);
                 else
@@ -468,14 +473,18 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
         }
     }
     __syncthreads(); // (orders the scans' global stores before the block's reads of them)
-    const int gid = w * gpw + l / L; // (utterance of the block, chunk) = (gid / CB_CH, gid % CB_CH)
-    const bool again = combine_group<L, WANT_BETA, false>(blockIdx.x * (CB_CH * gpw) + gid, l % L, N, U, delta, A, off,
-                                       alpha, scale, wrow, sb, beta, gamma, part_xi, part_dena, part_denc, sink,
-                                       lognorm, lpart, logk, order, (int *)nullptr, 0, (int *)nullptr, (int *)nullptr);
-    if (again && (l % L) == 0) fix_flag[gid / CB_CH] = 1;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; pass++) {
+        const int gid = (pass * CB_CH + w) * gpw + l / L; // (utterance of the block, chunk) = (gid / CB_CH, gid % CB_CH)
+        const bool again = combine_group<L, WANT_BETA, false>(blockIdx.x * (SC_UPB * CB_CH) + gid, l % L, N, U, delta, A,
+                                           off, alpha, scale, wrow, sb, beta, gamma, part_xi, part_dena, part_denc,
+                                           sink, lognorm, lpart, logk, order, (int *)nullptr, 0, (int *)nullptr,
+                                           (int *)nullptr);
+        if (again && (l % L) == 0) fix_flag[gid / CB_CH] = 1;
+    }
     __syncthreads();
-    if (w != 0) return;
-    const int g = l / L, slot = blockIdx.x * gpw + g;
+    if (w >= SC_UPB / gpw) return; // wave w takes the listed ones among utterances w gpw .. w gpw + gpw - 1
+    const int g = w * gpw + l / L, slot = blockIdx.x * SC_UPB + g;
     if (slot >= U || !fix_flag[g]) return;
     fix_in_block<L>(N, U, delta, order[slot], l % L, A, b, off, alpha, scale, beta, gamma, part_xi, part_dena, part_denc,
                     wave_sink(sink), fix_cnt);
