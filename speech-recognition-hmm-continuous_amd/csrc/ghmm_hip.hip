@@ -1045,10 +1045,13 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
     }
     double *post = want_post ? ctx->post : nullptr;
     const bool sched_ok = m->mfma_ok && ctx->kernels != 1 &&
-                          (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) && m->DP == 40;
+                          (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) &&
+                          (m->DP == 40 || m->DP == 28 || m->DP == 16);
     if ((mode == 2 || mode == 0) && sched_ok) {
-        // The scheduled matrix-core kernel: compile-time K steps (D = 36..39 -> KS = 20) and
-        // mixture padding.  It needs no fallback launch: a Gaussian that is ill-conditioned even
+        // The scheduled matrix-core kernel: compile-time K steps — D = 36..39 -> KS = 20, 24..27 ->
+        // 14, 12..15 -> 8: the classic 12/13-coefficient cepstra with and without their first and
+        // second differences (its direct-operand variant reads columns 4 s + kq < 4 (KS / 2 - 1) + 4
+        // unclamped, so D must reach into the last group of four) — and mixture padding.  It needs no fallback launch: a Gaussian that is ill-conditioned even
         // around its tile's offset is re-evaluated in direct form inside the kernel, for the few
         // frames where its density is not 0.
         int rc;
@@ -1063,13 +1066,19 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
         const double *wk = mode == 2 ? m->logwkp : m->wkp; // OUT = 2 adds log wk to the exponents
         const int ntp = nt_posteriors(ctx, m, c) ? 1 : 0; // non-temporal posterior stores
         kscope ks(ctx, GHMM_K_EMISSION);
-#define GHMM_EMS(MP, PO)                                                                          \
+#define GHMM_EMSK(KSV, MP, PO)                                                                    \
     do {                                                                                          \
-        if ((rc = lds_attr(ctx, (const void *)k_emission_sched<20, MP, PO>))) return rc;         \
-        hipLaunchKernelGGL((k_emission_sched<20, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
+        if ((rc = lds_attr(ctx, (const void *)k_emission_sched<KSV, MP, PO>))) return rc;        \
+        hipLaunchKernelGGL((k_emission_sched<KSV, MP, PO>), dim3((unsigned)gxs, (unsigned)chunks), \
                            dim3((unsigned)(wv * WAVE)), lds_s, ctx->stream, m->N, m->M, m->D, m->NT, \
                            tcs, c->F, c->X, m->Wm, m->oglob, wk, m->gmap, ctx->b, post, m->dtile, \
                            m->tshift, m->tfull, m->condt, m->mean, m->inv_var, ntp);              \
+    } while (0)
+#define GHMM_EMS(MP, PO)                                                                          \
+    do {                                                                                          \
+        if (m->DP == 40) GHMM_EMSK(20, MP, PO);                                                   \
+        else if (m->DP == 28) GHMM_EMSK(14, MP, PO);                                              \
+        else GHMM_EMSK(8, MP, PO);                                                                \
     } while (0)
 #define GHMM_EMS3(MP)                                                                             \
     do {                                                                                          \
