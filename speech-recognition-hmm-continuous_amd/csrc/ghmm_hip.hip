@@ -1393,16 +1393,30 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
     // fold buffer: three of the four register rows of every tile, four waves (ghmm_mfma.hpp, end of k_mixstats_mfma)
     const size_t fold = (size_t)CT * NE * 4 * 3 * 64 * sizeof(double);
     // staged variant: every chunk of CT tiles must map to an even-aligned, even-length run of
-    // real Gaussians (true when no mixture padding: Mp == M, M even) and N <= 32 (two 16-byte
-    // gamma pieces per lane and stage up to 16 states, four beyond)
+    // real Gaussians that starts in the first slot of its first tile (mixture padding and odd
+    // mixture counts included: 10 x 3, 10 x 5 ... qualify, 5 x 3 with its 15 Gaussians does not) and
+    // N <= 32 (two 16-byte gamma pieces per lane and stage up to 16 states, four beyond)
     const int G = m->N * m->M;
-    const bool staged = (((unsigned long long)c->X) & 15ull) == 0 && // (its frame pieces are 16-byte loads)
-                        m->Mp == m->M && (m->M % 2) == 0 && m->N <= 32 && (G % 2) == 0 &&
-                        ((CT * 16) % 2) == 0 && ctx->kernels != 3;
+    bool staged = (((unsigned long long)c->X) & 15ull) == 0 && // (its frame pieces are 16-byte loads)
+                  m->N <= 32 && (G % 2) == 0 && chunks <= 64 && ctx->kernels != 3;
+    int cg0[64], cgw[64], GWmax = 0; // per chunk: first real Gaussian, number of real Gaussians
+    for (int ch = 0; staged && ch < chunks; ch++) {
+        const int p0 = ch * CT * 16, p1 = (ch + 1) * CT * 16 < m->NT * 16 ? (ch + 1) * CT * 16 : m->NT * 16;
+        int first = -1, n = 0;
+        for (int gp = p0; gp < p1; gp++)
+            if (gp / m->Mp < m->N && gp % m->Mp < m->M) {
+                if (first < 0) first = (gp / m->Mp) * m->M + gp % m->Mp;
+                n++;
+            }
+        const bool head_real = p0 / m->Mp < m->N && p0 % m->Mp < m->M;
+        if (n == 0 || !head_real || (first % 2) != 0 || (n % 2) != 0) staged = false;
+        cg0[ch] = first;
+        cgw[ch] = n;
+        if (n > GWmax) GWmax = n;
+    }
     const bool wide = m->N > 16;
     int rc;
     if (staged) {
-        const int GWmax = CT * 16 < G ? CT * 16 : G;
         size_t stage = (size_t)MSM_WAVES * (16 * (NE * 16 + GWmax + m->N) + m->DP) * sizeof(double);
         size_t lds = stage > fold ? stage : fold;
         if (lds <= 150 * 1024) {
@@ -1429,8 +1443,7 @@ static int launch_mixstats_mfma(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, in
     } while (0)
             // one launch per chunk so that gmin / GW are plain arguments (chunks == 1 at 10x8)
             for (int ch = 0; ch < chunks; ch++) {
-                const int gmin = ch * CT * 16;
-                const int GW = G - gmin < CT * 16 ? G - gmin : CT * 16;
+                const int gmin = cg0[ch], GW = cgw[ch];
                 if constexpr (NE == 5) {
                     if (masked) {
                         if (wide) GHMM_MIXSTATS(CT, NE, true, true, false, 4);

@@ -1382,7 +1382,8 @@ constexpr int MSM_PD = 4; // k-steps of operands in flight per wave
 
 // STAGED = true: frames go HBM -> registers -> LDS in 16-frame stages with fully
 // coalesced 16-byte-per-lane loads (one stage ahead), MFMA operands come from LDS.
-// Needs G, gmin, GW even (16-byte alignment of the posterior rows) and N <= 8 NGL (<= 32: the
+// Needs G and every chunk's gmin, GW even (16-byte alignment of the posterior rows' pieces; mixture
+// padding and odd mixture counts are fine otherwise) and N <= 8 NGL (<= 32: the
 // state masks are 32-bit words).
 // STAGED = false: operands straight from HBM, 8 bytes per lane (any shape).
 // MASKED (staged only): the states that carry weight in every 16-frame stage come from
@@ -1408,7 +1409,9 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
     const int tid = threadIdx.x, l = tid & 63, j = l & 15, kq = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index, in a scalar register
     const int G = N * M, ES = NE * 16;
-    const int c0 = STAGED ? gmin / 16 : blockIdx.y * CT; // staged: one launch per chunk
+    // staged: one launch per chunk; gmin = the chunk's first REAL Gaussian, which sits in the first
+    // slot of the chunk's first tile (the host checks): its padded position gives the tile
+    const int c0 = STAGED ? ((gmin / M) * Mp + gmin % M) / 16 : blockIdx.y * CT;
     int gmA[CT], stA[CT];
     const float rMp = 1.0f / (float)Mp, rM = 1.0f / (float)M, rN = 1.0f / (float)N;
 #pragma unroll
@@ -1457,7 +1460,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
                    // that hipcc cannot sink the loads under a branch
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-        gmC[c] = gmA[c] >= 0 ? gmA[c] : 0;
+        gmC[c] = gmA[c] >= 0 ? gmA[c] : (STAGED ? gmin : 0); // (padding: the chunk's first column, times 0)
         stA[c] = stA[c] < N ? stA[c] : 0;
         mk[c] = gmA[c] >= 0 ? 1.0 : 0.0;
     }
@@ -1502,7 +1505,7 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
         v2d rx[NXL], rp[NPL], rg[NGL], rgn[NGL];
         unsigned offp[NPL]; // posterior piece -> element offset inside a stage (rows strided by G)
         unsigned pcp[NPL], pcx[NXL], pcg[NGL]; // clamped piece indices
-        unsigned pst[NPL];                     // state of the piece's two Gaussians (M even)
+        unsigned pst[NPL];                     // state of the piece's first Gaussian
         unsigned offpB[NPL], pbit[NPL], pcxB[NXL]; // byte offsets inside a stage, state bit, frame piece bytes
         unsigned gb0[NGL], gb1[NGL];           // state bits of the two gammas of a piece
         // the first two stages' gammas are asked for before anything else: the tables below are
@@ -1531,7 +1534,8 @@ k_mixstats_mfma(int N, int M, int Mp, int D, int DP, int NT, long long F, int gm
             offp[u] = (unsigned)(row * G + gmin + 2 * c2);
             pst[u] = (unsigned)div_small(gmin + 2 * c2, M, rM);
             offpB[u] = (offp[u] - (unsigned)gmin) * 8u;
-            pbit[u] = 1u << pst[u];
+            // (an odd mixture count puts the piece's two Gaussians in two states now and then)
+            pbit[u] = (1u << pst[u]) | (1u << (unsigned)div_small(gmin + 2 * c2 + 1, M, rM));
         }
 #pragma unroll
         for (int u = 0; u < NGL; u++) {
