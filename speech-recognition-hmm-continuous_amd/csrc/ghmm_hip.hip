@@ -1046,12 +1046,11 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
     double *post = want_post ? ctx->post : nullptr;
     const bool sched_ok = m->mfma_ok && ctx->kernels != 1 &&
                           (m->Mp <= 16 || m->Mp == 32 || m->Mp == 64) &&
-                          (m->DP == 40 || m->DP == 28 || m->DP == 16);
+                          m->DP >= 8 && m->DP <= 48;
     if ((mode == 2 || mode == 0) && sched_ok) {
-        // The scheduled matrix-core kernel: compile-time K steps — D = 36..39 -> KS = 20, 24..27 ->
-        // 14, 12..15 -> 8: the classic 12/13-coefficient cepstra with and without their first and
-        // second differences (its direct-operand variant reads columns 4 s + kq < 4 (KS / 2 - 1) + 4
-        // unclamped, so D must reach into the last group of four) — and mixture padding.  It needs no fallback launch: a Gaussian that is ill-conditioned even
+        // The scheduled matrix-core kernel: compile-time K steps, KS = DP / 2 for D = 4 .. 47 (DP = D + 1
+        // rounded up to a multiple of four, so D always reaches into the last group of four columns,
+        // which its direct-operand variant reads unclamped up to there) — and mixture padding.  It needs no fallback launch: a Gaussian that is ill-conditioned even
         // around its tile's offset is re-evaluated in direct form inside the kernel, for the few
         // frames where its density is not 0.
         int rc;
@@ -1076,9 +1075,19 @@ static int run_emission(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int mode, 
     } while (0)
 #define GHMM_EMS(MP, PO)                                                                          \
     do {                                                                                          \
-        if (m->DP == 40) GHMM_EMSK(20, MP, PO);                                                   \
-        else if (m->DP == 28) GHMM_EMSK(14, MP, PO);                                              \
-        else GHMM_EMSK(8, MP, PO);                                                                \
+        switch (m->DP) {                                                                          \
+        case 8: GHMM_EMSK(4, MP, PO); break;                                                      \
+        case 12: GHMM_EMSK(6, MP, PO); break;                                                     \
+        case 16: GHMM_EMSK(8, MP, PO); break;                                                     \
+        case 20: GHMM_EMSK(10, MP, PO); break;                                                    \
+        case 24: GHMM_EMSK(12, MP, PO); break;                                                    \
+        case 28: GHMM_EMSK(14, MP, PO); break;                                                    \
+        case 32: GHMM_EMSK(16, MP, PO); break;                                                    \
+        case 36: GHMM_EMSK(18, MP, PO); break;                                                    \
+        case 40: GHMM_EMSK(20, MP, PO); break;                                                    \
+        case 44: GHMM_EMSK(22, MP, PO); break;                                                    \
+        default: GHMM_EMSK(24, MP, PO); break;                                                    \
+        }                                                                                         \
     } while (0)
 #define GHMM_EMS3(MP)                                                                             \
     do {                                                                                          \
