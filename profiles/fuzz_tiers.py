@@ -30,7 +30,7 @@ for seed in range(n):
         out[tier] = dict(stats=stats.download(), gamma=ctx.fetch(G.BUF_GAMMA, (F, N)),
                          beta=ctx.fetch(G.BUF_BETA, (F, N)), ll=ctx.fetch(G.BUF_LOGLIK, (len(lens),)))
         stats.close()
-    # the default tier with its recursions in separate launches (GHMM_OPT_FUSED_SCAN 2): bit for bit
+    # the default tier with its recursions in separate launches (GHMM_OPT_FUSED_SCAN 2): per-frame results bit for bit
     ctx.set_option(G.OPT_FUSED_SCAN, 2)
     stats = ctx.stats(N, M, D)
     ctx.estep(model, corpus, stats)
@@ -39,7 +39,16 @@ for seed in range(n):
     stats.close()
     ctx.set_option(G.OPT_FUSED_SCAN, 0)
     for k in ("ll", "gamma", "beta", "stats"):
-        if not np.array_equal(out[0][k], sep[k], equal_nan=True):
+        # (log P and the statistics are sums over an utterance's chunks: fewer chunks in the one launch
+        # when the utterances are short)
+        same = np.array_equal(out[0][k], sep[k], equal_nan=True)
+        if not same and k in ("ll", "stats") and np.array_equal(np.isnan(out[0][k]), np.isnan(sep[k])):
+            try:
+                T.assert_close(out[0][k], sep[k], rtol=1e-12, what=k)
+                same = True
+            except AssertionError:
+                pass
+        if not same:
             bad += 1
             print(f"seed {seed}: N={N} M={M} D={D} lens={list(lens)} dense={dense} delta={delta} robust={robust}: {k}: one launch and separate launches differ")
     for k in ("ll", "gamma", "beta", "stats"):

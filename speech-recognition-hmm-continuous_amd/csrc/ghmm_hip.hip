@@ -83,6 +83,7 @@ struct ghmm_ctx {
     int *hflag_page = nullptr, *hflag_page_dev = nullptr;
     unsigned long long hflag_used = 0;
     bool loglik_pieces = false; // log P of the last E-step is in lpart / logk, loglik[] not assembled
+    int lp_nch = 0;             // chunks per utterance of those pieces
     bool own_bwd_done = false; // k_scan_pair ran the backward direction for the current alpha
     bool beta_valid = false;   // ctx->beta holds the reference's beta^
     // what the last gamma / xi pass ran on, so that ghmm_fetch(GHMM_BUF_BETA) can form beta^ when
@@ -1309,6 +1310,7 @@ static int run_backward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool want_
                 else GHMM_BY_LANES(L, GHMM_COMBINE(LL, false, true));
             }
             if ((rc = run_backward_fix(ctx, m, c, L, blocks, CB_CH, nullptr))) return rc;
+            ctx->lp_nch = CB_CH;
             ctx->beta_valid = want_beta;
             ctx->last_m = m;
             ctx->last_c = c;
@@ -1339,8 +1341,18 @@ static int run_scan_combine(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool *
     if (c->U == 0 || !use_pair(ctx, m) || ctx->fused_scan == 2) return GHMM_OK;
     if ((rc = fb_lanes(m, &L))) return rc;
     const bool band2 = m->banded && ctx->delta <= 1;
-    const unsigned blocks = (unsigned)((c->U + SC_UPB - 1) / SC_UPB);
     if (!band2) return GHMM_OK;
+    // utterances per block: more of them, in fewer chunks each, the shorter they are (a 30-frame word
+    // in eight chunks is all set-up, and the reduction then reads 8 slots per word) — as far as
+    // the block's eight waves can scan them (2 upb / (WAVE / L) <= 8)
+    int upb = SC_UPB;
+    {
+        const long long tmean = c->F / c->U;
+        const int want = tmean >= 160 ? SC_UPB : (tmean >= 80 ? 2 * SC_UPB : 4 * SC_UPB);
+        while (upb < want && 2 * (2 * upb) / (WAVE / L) <= CB_CH) upb *= 2;
+    }
+    const int nch = SC_GROUPS / upb;
+    const unsigned blocks = (unsigned)((c->U + upb - 1) / upb);
     ctx->own_bwd_done = true;
     ctx->loglik_pieces = true; // the combine phase takes the logs of log P
     if (++ctx->fix_stamp == 0x7fffffff) { // (2^31 passes: start the marks over)
@@ -1351,7 +1363,7 @@ static int run_scan_combine(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool *
     {
         kscope ks(ctx, GHMM_K_FORWARD);
         GHMM_BY_LANES(L, hipLaunchKernelGGL((k_scan_combine<LL, false>), dim3(blocks), dim3(CB_CH * WAVE), 0, ctx->stream,
-                                            m->N, c->U, (int)ctx->delta, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
+                                            m->N, c->U, (int)ctx->delta, upb, m->A, ctx->b, c->off, ctx->alpha, ctx->scale,
                                             ctx->wrow, ctx->sb, ctx->beta, ctx->gamma, ctx->part_xi, ctx->part_dena,
                                             ctx->part_denc, ctx->sink,
                                             ctx->robust ? ctx->lognorm : (const double *)nullptr, ctx->lpart, ctx->logk,
@@ -1359,10 +1371,11 @@ static int run_scan_combine(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool *
                                             ctx->fix_cnt + ((ctx->fix_stamp + 1) & 1)));
     }
     if ((rc = launch_ok("k_scan_combine"))) return rc;
+    ctx->lp_nch = nch;
     ctx->beta_valid = false; // beta^ on demand (ghmm_fetch)
     ctx->last_m = m;
     ctx->last_c = c;
-    ctx->slots = c->U * CB_CH;
+    ctx->slots = c->U * nch;
     *done = true;
     return GHMM_OK;
 }
@@ -1649,7 +1662,7 @@ static int fetch_impl(ghmm_ctx *ctx, int which, bool whole, size_t first, double
     case GHMM_BUF_LOGLIK:
         if (ctx->loglik_pieces && ctx->loglik && U) {
             hipLaunchKernelGGL(k_loglik_assemble, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (int)U, ctx->lpart, ctx->logk, ctx->loglik);
+                               (int)U, ctx->lp_nch, ctx->lpart, ctx->logk, ctx->loglik);
             ctx->loglik_pieces = false; // loglik[] is complete now (the pieces stay valid too)
         }
         src = ctx->loglik;

@@ -38,7 +38,8 @@ namespace ghmm {
 #define GHMM_CB_CH 8 // (measurement builds override it: profiles/tools/lab.sh)
 #endif
 constexpr int CB_CH = GHMM_CB_CH; // chunks of an utterance handled by different groups of k_combine
-constexpr int SC_UPB = 4; // utterances per block of k_scan_combine
+constexpr int SC_UPB = 4;     // utterances per block of k_scan_combine, at least
+constexpr int SC_GROUPS = SC_UPB * GHMM_CB_CH; // its combine groups = utterances x chunks per utterance
 constexpr int CB_PF = 4; // frames of operands read ahead in k_combine (x 2 register sets x 4 operands)
 // rows of beta~ are scaled to a sum in [2^BT_K, 2^(BT_K+1)): W = b beta~ stays finite for densities
 // up to 1e100 (a 39-d Gaussian at the 1e-5 variance floor peaks at 1e82) and keeps 512 decades
@@ -323,16 +324,16 @@ __device__ __forceinline__ bool combine_group(int qs, int i, int N, int U, int d
           double *__restrict__ part_denc, double *__restrict__ sink,
           const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
           const int *__restrict__ order, int *__restrict__ fix_mark, int stamp, int *__restrict__ fix_cnt,
-          int *__restrict__ fix_list)
-{
-    const int k = qs % CB_CH;
-    if (qs / CB_CH >= U) return false;
-    const int u = order[qs / CB_CH]; // longest utterances first
-    const int q = u * CB_CH + k;     // partial-sum slot of (utterance, chunk)
+          int *__restrict__ fix_list, int nch = CB_CH)
+{   // nch = chunks per utterance: CB_CH in k_combine's launch, 2 .. CB_CH in k_scan_combine's
+    const int k = qs % nch;
+    if (qs / nch >= U) return false;
+    const int u = order[qs / nch]; // longest utterances first
+    const int q = u * nch + k;     // partial-sum slot of (utterance, chunk)
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     const bool act = i < N;
-    const int tlo = (int)((long long)T * k / CB_CH), thi = (int)((long long)T * (k + 1) / CB_CH);
+    const int tlo = (int)((long long)T * k / nch), thi = (int)((long long)T * (k + 1) / nch);
     if (lpart) {
         // calc_probability (TF:1536-1553) in pieces: this chunk's -sum log c_t (+ the robust
         // mode's normalisers), and log alpha^_{T-1}(N-1) from the chunk that ends the utterance
@@ -345,14 +346,14 @@ __device__ __forceinline__ bool combine_group(int qs, int i, int N, int U, int d
         lp = group_sum<L>(lp - pc.log_value());
         if (i == 0) {
             lpart[q] = lp;
-            if (k == CB_CH - 1) logk[u] = T > 0 ? log(alpha[(f0 + T - 1) * N + (N - 1)]) : 0.0;
+            if (k == nch - 1) logk[u] = T > 0 ? log(alpha[(f0 + T - 1) * N + (N - 1)]) : 0.0;
         }
     }
     if (T <= 0 || thi <= tlo) {
         if (act) {
-            for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(q, i, o, U * CB_CH)] = 0.0;
-            part_dena[pden_at(q, i, U * CB_CH)] = 0.0;
-            part_denc[pden_at(q, i, U * CB_CH)] = 0.0;
+            for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(q, i, o, U * nch)] = 0.0;
+            part_dena[pden_at(q, i, U * nch)] = 0.0;
+            part_denc[pden_at(q, i, U * nch)] = 0.0;
         }
         return false;
     }
@@ -368,11 +369,11 @@ __device__ __forceinline__ bool combine_group(int qs, int i, int N, int U, int d
     if (banded)
         again = combine_run<L, true, WANT_BETA, DENSE ? MAX_DELTA : 1>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                         wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
-                                        part_dena, part_denc, snk, U * CB_CH);
+                                        part_dena, part_denc, snk, U * nch);
     else if (DENSE)
         again = combine_run<L, false, WANT_BETA>(N, T, delta, i, act, q, tlo, thi, A, alpha + f0 * N, scale + f0,
                                          wrow + f0 * N, sb + f0, beta + f0 * N, gamma + f0 * N, part_xi,
-                                         part_dena, part_denc, snk, U * CB_CH);
+                                         part_dena, part_denc, snk, U * nch);
     // the utterance goes on k_backward_fix's list once, whichever of its chunks asks first
     // (marks carry the pass's stamp: nothing is ever cleared)
     if (fix_mark && again && i == 0 && atomicExch(&fix_mark[u], stamp) != stamp) fix_list[atomicAdd(fix_cnt, 1)] = u;
@@ -411,21 +412,21 @@ __device__ __noinline__ void fix_in_block(int N, int U, int delta, int u, int i,
                                           double *__restrict__ beta, double *__restrict__ gamma,
                                           double *__restrict__ part_xi, double *__restrict__ part_dena,
                                           double *__restrict__ part_denc, double *__restrict__ snk,
-                                          int *__restrict__ fix_cnt)
+                                          int *__restrict__ fix_cnt, int nch)
 {
     const long long f0 = off[u];
     const int T = (int)(off[u + 1] - f0);
     if (T <= 0) return;
     const bool act = i < N;
-    const int S = U * CB_CH;
-    backward_run<L, false>(N, T, delta, i, act, u * CB_CH, A, b + f0 * N, alpha + f0 * N, scale + f0,
+    const int S = U * nch;
+    backward_run<L, false>(N, T, delta, i, act, u * nch, A, b + f0 * N, alpha + f0 * N, scale + f0,
                            (const double *)nullptr, beta + f0 * N, gamma + f0 * N, part_xi, part_dena, part_denc,
                            snk, S);
     if (act)
-        for (int k = 1; k < CB_CH; k++) {
-            for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(u * CB_CH + k, i, o, S)] = 0.0;
-            part_dena[pden_at(u * CB_CH + k, i, S)] = 0.0;
-            part_denc[pden_at(u * CB_CH + k, i, S)] = 0.0;
+        for (int k = 1; k < nch; k++) {
+            for (int o = 0; o <= MAX_DELTA; o++) part_xi[pxi_at(u * nch + k, i, o, S)] = 0.0;
+            part_dena[pden_at(u * nch + k, i, S)] = 0.0;
+            part_denc[pden_at(u * nch + k, i, S)] = 0.0;
         }
     if (i == 0) atomicAdd(fix_cnt, 1);
 }
@@ -436,7 +437,7 @@ __device__ __noinline__ void fix_in_block(int N, int U, int delta, int u, int i,
 // the next pass (as k_backward_fix does behind k_combine).
 template <int L, bool WANT_BETA>
 __global__ void __launch_bounds__(CB_CH *WAVE)
-k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const double *__restrict__ b,
+k_scan_combine(int N, int U, int delta, int upb, const double *__restrict__ A, const double *__restrict__ b,
                const long long *__restrict__ off, double *__restrict__ alpha, double *__restrict__ scale,
                double *__restrict__ wrow, double *__restrict__ sb, double *__restrict__ beta,
                double *__restrict__ gamma, double *__restrict__ part_xi, double *__restrict__ part_dena,
@@ -444,17 +445,20 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
                const double *__restrict__ lognorm, double *__restrict__ lpart, double *__restrict__ logk,
                const int *__restrict__ order, int *__restrict__ fix_cnt, int *__restrict__ fix_cnt_next)
 {
-    // SC_UPB utterances per block whatever the group width: 2 (L = 16), 4 (32) or 8 (64) scan
-    // waves — forward and backward of WAVE / L utterances each — and the block's SC_UPB x CB_CH
-    // combine groups in 1, 2 or 4 passes of its eight waves.  (With WAVE / L utterances per block a
-    // 20-state model made 500 blocks of 1 000 utterances, two rounds over the compute units.)
-    constexpr int gpw = WAVE / L, NSW = 2 * (SC_UPB / gpw), PASSES = SC_UPB * CB_CH / (CB_CH * gpw);
-    __shared__ int fix_flag[SC_UPB];
+    // upb = SC_UPB (4), 8 or 16 utterances per block (the host: more of them, in fewer chunks each,
+    // the shorter they are): 2 upb / gpw scan waves — forward and backward of WAVE / L utterances
+    // each, at most the block's eight — and upb x nch = SC_GROUPS combine groups in 1, 2 or 4 passes
+    // of the eight waves.  (With WAVE / L utterances per block a 20-state model made 500 blocks of
+    // 1 000 utterances, two rounds over the compute units; with eight chunks for a 30-frame word
+    // the combine pass was all set-up and the reduction read 80 000 slots.)
+    constexpr int gpw = WAVE / L, PASSES = SC_GROUPS / (CB_CH * gpw);
+    __shared__ int fix_flag[SC_GROUPS / 2];
+    const int nch = SC_GROUPS / upb, nsw = 2 * (upb / gpw);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), l = threadIdx.x % WAVE;
-    if (threadIdx.x < SC_UPB) fix_flag[threadIdx.x] = 0;
+    if (threadIdx.x < SC_GROUPS / 2) fix_flag[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *fix_cnt_next = 0; // the counter of the next pass
-    if (w < NSW) {
-        const int slot = blockIdx.x * SC_UPB + (w >> 1) * gpw + l / L;
+    if (w < nsw) {
+        const int slot = blockIdx.x * upb + (w >> 1) * gpw + l / L;
         const int i = l % L;
         if (slot < U) {
             const int u = order[slot];
@@ -463,7 +467,7 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
             if (T > 0) {
                 // (the scan waves' sink regions side by side: through wave_sink they would sit 8 KB
                 // apart, one per block, on a fraction of the L2 channels)
-                double *snk = sink + (size_t)((blockIdx.x * NSW + w) % SINK_WAVES) * 2 * WAVE + l;
+                double *snk = sink + (size_t)((blockIdx.x * nsw + w) % SINK_WAVES) * 2 * WAVE + l;
                 if ((w & 1) == 0)
                     forward_run<L, true, false>(N, T, i, i < N, A, b + f0 * N, alpha + f0 * N, scale + f0,
                                                 (double *)nullptr, snk, N);
@@ -475,19 +479,20 @@ k_scan_combine(int N, int U, int delta, const double *__restrict__ A, const doub
     __syncthreads(); // (orders the scans' global stores before the block's reads of them)
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; pass++) {
-        const int gid = (pass * CB_CH + w) * gpw + l / L; // (utterance of the block, chunk) = (gid / CB_CH, gid % CB_CH)
-        const bool again = combine_group<L, WANT_BETA, false>(blockIdx.x * (SC_UPB * CB_CH) + gid, l % L, N, U, delta, A,
+        const int gid = (pass * CB_CH + w) * gpw + l / L; // (utterance of the block, chunk) = (gid / nch, gid % nch)
+        const bool again = combine_group<L, WANT_BETA, false>(blockIdx.x * SC_GROUPS + gid, l % L, N, U, delta, A,
                                            off, alpha, scale, wrow, sb, beta, gamma, part_xi, part_dena, part_denc,
                                            sink, lognorm, lpart, logk, order, (int *)nullptr, 0, (int *)nullptr,
-                                           (int *)nullptr);
-        if (again && (l % L) == 0) fix_flag[gid / CB_CH] = 1;
+                                           (int *)nullptr, nch);
+        if (again && (l % L) == 0) fix_flag[gid / nch] = 1;
     }
     __syncthreads();
-    if (w >= SC_UPB / gpw) return; // wave w takes the listed ones among utterances w gpw .. w gpw + gpw - 1
-    const int g = w * gpw + l / L, slot = blockIdx.x * SC_UPB + g;
+    // wave w takes the listed ones among utterances w gpw .. w gpw + gpw - 1 (+ 8 gpw, ... for upb > 8 gpw: never)
+    if (w >= upb / gpw) return;
+    const int g = w * gpw + l / L, slot = blockIdx.x * upb + g;
     if (slot >= U || !fix_flag[g]) return;
     fix_in_block<L>(N, U, delta, order[slot], l % L, A, b, off, alpha, scale, beta, gamma, part_xi, part_dena, part_denc,
-                    wave_sink(sink), fix_cnt);
+                    wave_sink(sink), fix_cnt, nch);
 }
 
 // The utterances k_combine listed, whole, in the reference's own order of operations:
@@ -536,13 +541,13 @@ k_backward_fix(int N, int U, int delta, const double *__restrict__ A, const doub
 namespace ghmm {
 // log P per utterance from the pieces k_combine left (only when somebody asks for the vector)
 __global__ void __launch_bounds__(256)
-k_loglik_assemble(int U, const double *__restrict__ lpart, const double *__restrict__ logk,
+k_loglik_assemble(int U, int nch, const double *__restrict__ lpart, const double *__restrict__ logk,
                   double *__restrict__ loglik)
 {
     const int u = blockIdx.x * 256 + threadIdx.x;
     if (u >= U) return;
     double lp = 0.0;
-    for (int k = 0; k < CB_CH; k++) lp += lpart[(size_t)u * CB_CH + k];
+    for (int k = 0; k < nch; k++) lp += lpart[(size_t)u * nch + k];
     loglik[u] = lp + logk[u];
 }
 } // namespace ghmm

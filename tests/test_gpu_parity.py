@@ -1191,8 +1191,9 @@ def test_class2_gaussians_both_exact_paths(G, ctx):
 def test_one_launch_recursions_equal_the_separate_launches(G, ctx, shape):
     """k_scan_combine (both scans + the gamma / xi pass in one launch, what ghmm_estep uses on a
     band-diagonal A) against k_scan_pair + k_combine (GHMM_OPT_FUSED_SCAN = 2): the same
-    operations in the same order, so statistics, gamma, alpha^ and log P bit for bit; and beta^
-    on demand after either."""
+    operations per frame, so gamma, alpha^ and beta^ (on demand after either) bit for bit; the
+    statistics and log P are sums over an utterance's chunks, of which the one launch makes fewer
+    when the utterances are short."""
     N, M, D, lens = shape
     hm, X, lens = synth_case(G, N, M, D, lens, seed=N)
     corpus = ctx.corpus(X, lens)
@@ -1207,7 +1208,11 @@ def test_one_launch_recursions_equal_the_separate_launches(G, ctx, shape):
                          ctx.fetch(G.BUF_LOGLIK, (len(lens),)), ctx.fetch(G.BUF_BETA, (F, N)))
             model.close(); stats.close()
         for a, b, nm in zip(out[2], out[0], ("statistics", "gamma", "alpha", "loglik", "beta")):
-            assert np.array_equal(a, b, equal_nan=True), nm
+            if nm in ("statistics", "loglik"):   # sums over an utterance's chunks: 8 there, 2 .. 8 here
+                assert np.array_equal(np.isnan(a), np.isnan(b)), nm
+                assert_close(b, a, rtol=1e-12, what=nm)
+            else:
+                assert np.array_equal(a, b, equal_nan=True), nm
         ref, _ = O.estep(hm, X, lens, dumps=False)
         assert_close(out[0][0], ref, what="statistics against the oracle")
     finally:
