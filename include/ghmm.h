@@ -253,7 +253,8 @@ int ghmm_estep(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_stats *stats);
  * becomes 0 / den_a = 0 as in the reference.  Asynchronous. */
 int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *stats);
 /* Forward-algorithm score per utterance (RF:354-366): emission without
- * posteriors + alpha + log P.  Synchronises, writes loglik[U] on the host. */
+ * posteriors + the forward recursion + log P.  Synchronises, writes loglik[U] on the host.
+ * (Only log P is kept: alpha^ and c_t stay in registers; ghmm_forward leaves them in the workspace.) */
 int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *loglik_host);
 /* The recogniser's whole vocabulary loop (RF:326-374) in two launches: ONE emission launch
  * over the concatenated Gaussians of all `n_models` word models and ONE forward launch

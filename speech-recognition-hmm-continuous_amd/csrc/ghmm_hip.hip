@@ -74,6 +74,11 @@ struct ghmm_ctx {
     // kernel of pass n zeroes the counter of pass n + 1)
     int *fix_mark = nullptr, *fix_list = nullptr, *fix_cnt = nullptr;
     int *wide_flag = nullptr; // models of more than 64 states: A (or log A) has entries off the band
+    // ghmm_score_batch: the concatenated vocabulary model and the pass's tables, kept between calls
+    ghmm_model *bt_cat = nullptr;
+    char *bt_tab = nullptr;
+    double *bt_scale = nullptr, *bt_sinv = nullptr, *bt_ll = nullptr;
+    size_t cap_bt_tab = 0, cap_bt_scale = 0, cap_bt_sinv = 0, cap_bt_ll = 0;
     size_t cap_fix_mark = 0, cap_fix_list = 0;
     int fix_stamp = 0;
     long long launch_mark = 0, sync_mark = 0; // preparations enqueued / covered by a completed wait (stream_sync)
@@ -370,7 +375,11 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    void *bufs[] = {ctx->b_alloc, ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
+    if (ctx->bt_cat) {
+        ghmm_model_destroy(ctx, ctx->bt_cat);
+        ctx->bt_cat = nullptr;
+    }
+    void *bufs[] = {ctx->bt_tab, ctx->bt_scale, ctx->bt_sinv, ctx->bt_ll, ctx->b_alloc, ctx->post,      ctx->alpha,     ctx->beta,    ctx->gamma,
                     ctx->scale,   ctx->lognorm,   ctx->loglik,    ctx->part_xi, ctx->part_dena,
                     ctx->part_denc, ctx->part_mu, ctx->part_var,  ctx->psi,     ctx->path,
                     ctx->part_m,  ctx->sinv,      ctx->sink,      ctx->wrow,    ctx->sb,
@@ -1196,8 +1205,10 @@ static int wide_band_flag(ghmm_ctx *ctx, const ghmm_model *m, const double *A, d
 // (calc_alpha, then calc_beta scaled by its c_t) in the one-pass kernels.
 static bool use_pair(const ghmm_ctx *ctx, const ghmm_model *m) { return ctx->kernels != 1 && m->N <= 64; }
 
-static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_backward = false)
-{
+static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_backward = false,
+                       bool score_only = false)
+{   // score_only (ghmm_score): log P alone, alpha^ and c_t are not written
+
     if (c->U == 0) return GHMM_OK;
     int L, rc;
     if ((rc = fb_lanes(m, &L))) return rc;
@@ -1222,7 +1233,7 @@ static int run_forward(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, bool with_b
         kscope ks(ctx, GHMM_K_FORWARD);
         if (use_pair(ctx, m)) {
             const unsigned ny = with_backward ? 2u : 1u;
-            const int only = with_backward ? -1 : 0;
+            const int only = with_backward ? -1 : (score_only ? 2 : 0);
             GHMM_BY_LANES(L, hipLaunchKernelGGL(k_scan_pair<LL>, dim3(blocks, ny), dim3(WAVE), 0, ctx->stream, m->N, c->U,
                                                 only, m->A, ctx->b, c->off, ctx->alpha, ctx->scale, ctx->sinv, ln,
                                                 ctx->loglik, ctx->wrow, ctx->sb, ctx->sink, c->order));
@@ -1905,7 +1916,7 @@ extern "C" int ghmm_score(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, double *
     ARG_CHECK(loglik_host || c->U == 0, "null destination");
     if ((rc = ws_frames(ctx, m, c, false)) || (rc = ws_fb(ctx, m, c))) return rc;
     if ((rc = run_emission(ctx, m, c, ctx->robust ? 1 : 0, false))) return rc;
-    if ((rc = run_forward(ctx, m, c))) return rc;
+    if ((rc = run_forward(ctx, m, c, false, true))) return rc;
     if (c->U)
         HIP_TRY(hipMemcpyAsync(loglik_host, ctx->loglik, (size_t)c->U * 8, hipMemcpyDeviceToHost,
                                ctx->stream));
@@ -2047,86 +2058,73 @@ extern "C" int ghmm_score_batch(ghmm_ctx *ctx, ghmm_model *const *models, int n_
             if ((rc = ghmm_score(ctx, models[k], c, loglik_host + (size_t)k * c->U))) return rc;
         return GHMM_OK;
     }
-    // the concatenated model: NS states x M mixtures (transition matrix unused)
-    ghmm_model *cat = nullptr;
-    if ((rc = ghmm_model_create(ctx, NS, M, D, &cat))) return rc;
-    std::vector<fwd_model> tab((size_t)n_models);
-    size_t go = 0;
-    int so = 0;
-    hipError_t e = hipSuccess;
-    for (int k = 0; k < n_models && e == hipSuccess; k++) {
-        const ghmm_model *m = models[k];
-        const size_t g = (size_t)m->N * M;
-        e = hipMemcpyAsync(cat->c + go, m->c, g * 8, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(cat->mean + go * D, m->mean, g * D * 8, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(cat->inv_var + go * D, m->inv_var, g * D * 8, hipMemcpyDeviceToDevice,
-                               ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(cat->det + go, m->det, g * 8, hipMemcpyDeviceToDevice, ctx->stream);
-        tab[k].A = m->A;
-        tab[k].N = m->N;
-        tab[k].bo = so;
-        go += g;
-        so += m->N;
-    }
-    fwd_model *dtab = nullptr;
-    double *dscale = nullptr, *dsinv = nullptr, *dll = nullptr;
-    if (e == hipSuccess) e = hipMemsetAsync(cat->A, 0, (size_t)NS * NS * 8, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void **)&dtab, tab.size() * sizeof(fwd_model));
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(fwd_model), hipMemcpyHostToDevice,
-                           ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void **)&dscale, (size_t)n_models * c->F * 8 + 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&dsinv, (size_t)n_models * c->F * 8 + 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&dll, (size_t)n_models * c->U * 8);
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(ctx->stream);
-        if (dtab) (void)hipFree(dtab);
-        if (dscale) (void)hipFree(dscale);
-        if (dsinv) (void)hipFree(dsinv);
-        if (dll) (void)hipFree(dll);
-        ghmm_model_destroy(ctx, cat);
-    };
-    if (e != hipSuccess) {
-        ghmm_set_error("ghmm_score_batch: %s", hipGetErrorString(e));
-        cleanup();
-        return GHMM_ERR_HIP;
-    }
-    cat->epoch++;
-    if ((rc = model_prepare(ctx, cat, true)) || (rc = ws_frames(ctx, cat, c, false)) ||
-        (rc = run_emission(ctx, cat, c, ctx->robust ? 1 : 0, false))) {
-        cleanup();
-        return rc;
-    }
     if (ctx->robust) {
         // per-frame normalisation couples the models' densities; score them one by one
-        cleanup();
         for (int k = 0; k < n_models; k++)
             if ((rc = ghmm_score(ctx, models[k], c, loglik_host + (size_t)k * c->U))) return rc;
         return GHMM_OK;
     }
+    // The concatenated model: NS states x M mixtures (transition matrix unused).  It and the
+    // pass's tables live in the context from one call to the next (a recogniser scores batch after
+    // batch against one vocabulary: creating and freeing twenty device buffers per call was 0.75 ms
+    // of a 0.9 ms call); the words' parameters are gathered into it by ONE launch.
+    if (ctx->bt_cat && (ctx->bt_cat->N != NS || ctx->bt_cat->M != M || ctx->bt_cat->D != D)) {
+        ghmm_model_destroy(ctx, ctx->bt_cat);
+        ctx->bt_cat = nullptr;
+    }
+    if (!ctx->bt_cat) {
+        if ((rc = ghmm_model_create(ctx, NS, M, D, &ctx->bt_cat))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->bt_cat->A, 0, (size_t)NS * NS * 8, ctx->stream));
+    }
+    ghmm_model *cat = ctx->bt_cat;
+    std::vector<fwd_model> tab((size_t)n_models);
+    std::vector<gather_src> src((size_t)n_models);
+    {
+        int go = 0, so = 0;
+        for (int k = 0; k < n_models; k++) {
+            const ghmm_model *m = models[k];
+            tab[k].A = m->A;
+            tab[k].N = m->N;
+            tab[k].bo = so;
+            src[k].c = m->c; src[k].mean = m->mean; src[k].inv_var = m->inv_var; src[k].det = m->det;
+            src[k].g0 = go; src[k].ng = m->N * M;
+            go += m->N * M;
+            so += m->N;
+        }
+    }
+    const size_t tab_bytes = tab.size() * sizeof(fwd_model), src_bytes = src.size() * sizeof(gather_src);
+    if ((rc = dev_grow(&ctx->bt_tab, &ctx->cap_bt_tab, tab_bytes + src_bytes + 16))) return rc;
+    fwd_model *dtab = (fwd_model *)ctx->bt_tab;
+    gather_src *dsrc = (gather_src *)(ctx->bt_tab + ((tab_bytes + 15) / 16) * 16);
+    if ((rc = dev_grow(&ctx->bt_scale, &ctx->cap_bt_scale, (size_t)n_models * c->F + 1)) ||
+        (rc = dev_grow(&ctx->bt_sinv, &ctx->cap_bt_sinv, (size_t)n_models * c->F + 1)) ||
+        (rc = dev_grow(&ctx->bt_ll, &ctx->cap_bt_ll, (size_t)n_models * c->U)))
+        return rc;
+    // (the tables leave pageable host vectors: the copies complete before the call returns them)
+    HIP_TRY(hipMemcpyAsync(dtab, tab.data(), tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dsrc, src.data(), src_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather_models, dim3((unsigned)n_models), dim3(256), 0, ctx->stream, D, dsrc, cat->c,
+                       cat->mean, cat->inv_var, cat->det);
+    if ((rc = launch_ok("k_gather_models"))) return rc;
+    cat->epoch++;
+    cat->prep_mark = ++ctx->launch_mark;
+    if ((rc = model_prepare(ctx, cat, true)) || (rc = ws_frames(ctx, cat, c, false)) ||
+        (rc = run_emission(ctx, cat, c, 0, false)))
+        return rc;
     {
         const int L = Nmax <= 16 ? 16 : Nmax <= 32 ? 32 : 64, gpw = WAVE / L;
         const unsigned blocks = (unsigned)((c->U + gpw - 1) / gpw);
         kscope ks(ctx, GHMM_K_FORWARD);
         GHMM_BY_LANES(L, hipLaunchKernelGGL(k_forward_multi<LL>, dim3(blocks, (unsigned)n_models), dim3(WAVE), 0,
-                                            ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, dscale, dsinv, dll,
-                                            ctx->sink, c->order));
+                                            ctx->stream, c->U, NS, c->F, dtab, ctx->b, c->off, ctx->bt_scale,
+                                            ctx->bt_sinv, ctx->bt_ll, ctx->sink, c->order));
     }
-    rc = launch_ok("k_forward_multi");
-    if (!rc) {
-        e = hipMemcpyAsync(loglik_host, dll, (size_t)n_models * c->U * 8, hipMemcpyDeviceToHost,
-                           ctx->stream);
-        if (e != hipSuccess) {
-            ghmm_set_error("ghmm_score_batch: %s", hipGetErrorString(e));
-            rc = GHMM_ERR_HIP;
-        }
-    }
-    cleanup();
+    if ((rc = launch_ok("k_forward_multi"))) return rc;
+    HIP_TRY(hipMemcpyAsync(loglik_host, ctx->bt_ll, (size_t)n_models * c->U * 8, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(stream_sync(ctx));
     ctx->b_is_log = true; // the workspace b belongs to the concatenated model: not reusable
-    return rc;
+    return GHMM_OK;
 }
 
 extern "C" int ghmm_viterbi(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, int32_t *path_host,

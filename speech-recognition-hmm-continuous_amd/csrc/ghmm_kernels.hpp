@@ -339,6 +339,29 @@ __device__ inline double recip_fast(double s)
     return fma(r0, fma(-s, r0, 1.0), r0);
 }
 
+// -sum_t log c_t without a log per frame: the product of the mantissas and the sum of the exponents
+// (v_frexp_mant/exp + one multiply and one add per value), one log at the end.  0, inf and NaN
+// behave like log()'s sum: the mantissa of 0 / inf / NaN is itself.
+struct log_product {
+    double m = 1.0;
+    long long e = 0;
+    int n = 0;
+    __device__ inline void mul(double c)
+    {
+        m *= __builtin_amdgcn_frexp_mant(c);
+        e += __builtin_amdgcn_frexp_exp(c);
+        if (++n == 512) { // keep the product of mantissas (each in [0.5, 1)) away from underflow
+            e += __builtin_amdgcn_frexp_exp(m);
+            m = __builtin_amdgcn_frexp_mant(m);
+            n = 0;
+        }
+    }
+    __device__ inline double log_value() const
+    {
+        return fma((double)e, 6.93147180369123816490e-01, fma((double)e, 1.90821492927058770002e-10, log(m)));
+    }
+};
+
 template <int L, bool BANDED> struct fwd_state {
     double a, a_self, a_prev, a_next;
     double acol[BANDED ? 1 : L];
@@ -347,18 +370,22 @@ template <int L, bool BANDED> struct fwd_state {
     // the 16-lane sum off this chain via sum_j alpha^_{t-1}(j) g_j(t) was measured slower:
     // a lone wave per SIMD is bound by instruction count, ~13 cycles each, not by the chain.)
     // SINV: lane 1 keeps 1/c_t = sum_i alpha_t(i) for the reference-order backward pass
-    template <bool SINV>
-    __device__ inline void step_banded(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
+    // STORE_C = false (scoring only): c_t is not written; its logarithm's pieces are kept in `acc`
+    template <bool SINV, bool STORE_C>
+    __device__ inline void step_banded(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i,
+                                       log_product &acc)
     {
         const double v = fma(a, a_self, group_up1<L>(a) * a_prev) * bt;
         const double s = group_sum<L>(v);
         const double c = recip_fast(s);
         a = v * c;
         *pa = a;
-        *pcs = (SINV && i != 0) ? s : c;
+        if (STORE_C) *pcs = (SINV && i != 0) ? s : c;
+        else acc.mul(c);
     }
-    template <bool SINV>
-    __device__ inline void step_dense(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i)
+    template <bool SINV, bool STORE_C>
+    __device__ inline void step_dense(double bt, double *__restrict__ pa, double *__restrict__ pcs, int i,
+                                      log_product &acc)
     {
         double aux = 0.0;
 #pragma unroll
@@ -369,16 +396,18 @@ template <int L, bool BANDED> struct fwd_state {
         const double c = recip_select(s);
         a = v * c;
         *pa = a;
-        *pcs = (SINV && i != 0) ? s : c;
+        if (STORE_C) *pcs = (SINV && i != 0) ? s : c;
+        else acc.mul(c);
     }
 };
 
-template <int L, bool BANDED, bool SINV = true>
+template <int L, bool BANDED, bool SINV = true, bool STORE_C = true>
 __device__ __forceinline__ double forward_run(int N, int T, int i, bool act, const double *__restrict__ A,
                                      const double *__restrict__ bu, double *__restrict__ au,
                                      double *__restrict__ su, double *__restrict__ si,
-                                     double *__restrict__ sink, int bstride)
+                                     double *__restrict__ sink, int bstride, log_product *pacc = nullptr)
 {
+    log_product acc;
     fwd_state<L, BANDED> st;
     st.N = N;
     st.a_self = act ? A[i * N + i] : 0.0;
@@ -415,7 +444,8 @@ __device__ __forceinline__ double forward_run(int N, int T, int i, bool act, con
         const double c = recip_select(s);
         st.a = a0 * c;
         *pa = st.a;
-        *pcs = (SINV && i != 0) ? s : c;
+        if (STORE_C) *pcs = (SINV && i != 0) ? s : c;
+        else acc.mul(c);
         pa += da; pcs += dc;
     }
     double bq[PFF];
@@ -429,13 +459,13 @@ __device__ __forceinline__ double forward_run(int N, int T, int i, bool act, con
         if (BANDED) {
 #pragma unroll
             for (int k = 0; k < PFF; k++) {
-                st.template step_banded<SINV>(bq[k], pa, pcs, i);
+                st.template step_banded<SINV, STORE_C>(bq[k], pa, pcs, i, acc);
                 pa += da; pcs += dc;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < PFF; k++) {
-                st.template step_dense<SINV>(bq[k], pa, pcs, i);
+                st.template step_dense<SINV, STORE_C>(bq[k], pa, pcs, i, acc);
                 pa += da; pcs += dc;
             }
         }
@@ -446,40 +476,20 @@ __device__ __forceinline__ double forward_run(int N, int T, int i, bool act, con
     for (int k = 0; k < PFF - 1; k++)
         if (t + k < T) {
             if (BANDED) {
-                st.template step_banded<SINV>(bq[k], pa, pcs, i);
+                st.template step_banded<SINV, STORE_C>(bq[k], pa, pcs, i, acc);
             } else {
-                st.template step_dense<SINV>(bq[k], pa, pcs, i);
+                st.template step_dense<SINV, STORE_C>(bq[k], pa, pcs, i, acc);
             }
             pa += da; pcs += dc;
         }
+    if (!STORE_C && pacc) *pacc = acc;
     return st.a;
 }
 
-// -sum_t log c_t without a log per frame: the product of the mantissas and the sum of the exponents
-// (v_frexp_mant/exp + one multiply and one add per value), one log at the end.  0, inf and NaN
-// behave like log()'s sum: the mantissa of 0 / inf / NaN is itself.
-struct log_product {
-    double m = 1.0;
-    long long e = 0;
-    int n = 0;
-    __device__ inline void mul(double c)
-    {
-        m *= __builtin_amdgcn_frexp_mant(c);
-        e += __builtin_amdgcn_frexp_exp(c);
-        if (++n == 512) { // keep the product of mantissas (each in [0.5, 1)) away from underflow
-            e += __builtin_amdgcn_frexp_exp(m);
-            m = __builtin_amdgcn_frexp_mant(m);
-            n = 0;
-        }
-    }
-    __device__ inline double log_value() const
-    {
-        return fma((double)e, 6.93147180369123816490e-01, fma((double)e, 1.90821492927058770002e-10, log(m)));
-    }
-};
-
 // calc_alpha + calc_probability for utterance u on the 16/64 lanes of one group
-template <int L, bool SINV = true>
+// SCORE: log P only (ghmm_score) — alpha^ and c_t are not written, the logarithm of their product
+// is taken from its pieces in registers
+template <int L, bool SINV = true, bool SCORE = false>
 __device__ inline void forward_utt(int N, int u, int i, const double *__restrict__ A,
                                    const double *__restrict__ b, const long long *__restrict__ off,
                                    double *__restrict__ alpha, double *__restrict__ scale,
@@ -501,6 +511,21 @@ __device__ inline void forward_utt(int N, int u, int i, const double *__restrict
     double *su = scale + f0, *si = sinv + f0;
     double *snk = wave_sink(sink);
     double a;
+    if (SCORE) {
+        log_product pc;
+        if (banded)
+            a = forward_run<L, true, false, false>(N, T, i, act, A, b + f0 * N, nullptr, su, si, snk, N, &pc);
+        else
+            a = forward_run<L, false, false, false>(N, T, i, act, A, b + f0 * N, nullptr, su, si, snk, N, &pc);
+        double lp = 0.0;
+        if (lognorm) {
+            for (int t = i; t < T; t += L) lp += lognorm[f0 + t];
+            lp = group_sum<L>(lp);
+        }
+        const double last = __shfl(a, N - 1, L);
+        if (i == 0) loglik[u] = (lp - pc.log_value()) + log(last);
+        return;
+    }
     if (banded)
         a = forward_run<L, true, SINV>(N, T, i, act, A, b + f0 * N, alpha + f0 * N, su, si, snk, N);
     else
@@ -543,6 +568,27 @@ struct fwd_model {
     int N, bo;
 };
 
+// ghmm_score_batch: word model k's Gaussians (ng of them from g0) copied into the concatenated model
+struct gather_src {
+    const double *c, *mean, *inv_var, *det;
+    int g0, ng;
+};
+__global__ void __launch_bounds__(256)
+k_gather_models(int D, const gather_src *__restrict__ src, double *__restrict__ c, double *__restrict__ mean,
+                double *__restrict__ inv_var, double *__restrict__ det)
+{
+    const gather_src s = src[blockIdx.x];
+    for (int k = threadIdx.x; k < s.ng; k += 256) {
+        c[s.g0 + k] = s.c[k];
+        det[s.g0 + k] = s.det[k];
+    }
+    const size_t n = (size_t)s.ng * D, o = (size_t)s.g0 * D;
+    for (size_t k = threadIdx.x; k < n; k += 256) {
+        mean[o + k] = s.mean[k];
+        inv_var[o + k] = s.inv_var[k];
+    }
+}
+
 template <int L>
 __global__ void __launch_bounds__(WAVE)
 k_forward_multi(int U, int NS, long long F, const fwd_model *__restrict__ tab,
@@ -570,20 +616,18 @@ k_forward_multi(int U, int NS, long long F, const fwd_model *__restrict__ tab,
     for (int j = 0; j < N; j++)
         offband |= act && (A[j * N + i] != 0.0 && j != i && j != i - 1);
     const bool banded = !__any(offband);
-    double *su = scale + (size_t)k * F + f0, *si = sinv + (size_t)k * F + f0;
+    // (c_t is not written: 100 words x 150 000 frames of it were 240 MB per pass; the logarithm of
+    // the product comes from its pieces in registers)
     double *snk = wave_sink(sink);
     const double *bu = b + f0 * NS + mk.bo;
     double a;
+    log_product pc;
     if (banded)
-        a = forward_run<L, true>(N, T, i, act, A, bu, nullptr, su, si, snk, NS);
+        a = forward_run<L, true, false, false>(N, T, i, act, A, bu, nullptr, snk, snk, snk, NS, &pc);
     else
-        a = forward_run<L, false>(N, T, i, act, A, bu, nullptr, su, si, snk, NS);
-    __threadfence_block();
-    double lp = 0.0;
-    for (int t = i; t < T; t += L) lp -= log(su[t]);
-    lp = group_sum<L>(lp);
+        a = forward_run<L, false, false, false>(N, T, i, act, A, bu, nullptr, snk, snk, snk, NS, &pc);
     double last = __shfl(a, N - 1, L);
-    if (i == 0) loglik[(size_t)k * U + u] = lp + log(last);
+    if (i == 0) loglik[(size_t)k * U + u] = log(last) - pc.log_value();
 }
 
 // ----------------------------------------------------------------- backward

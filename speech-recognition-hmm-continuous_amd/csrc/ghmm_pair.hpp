@@ -132,6 +132,10 @@ k_scan_pair(int N, int U, int only, const double *__restrict__ A, const double *
     if (slot >= U) return;
     const int u = order[slot];
     const int dir = only >= 0 ? only : (int)blockIdx.y;
+    if (only == 2) { // log P only (ghmm_score): nothing but loglik[] is written
+        forward_utt<L, false, true>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink);
+        return;
+    }
     if (dir == 0) {
         // with the backward direction alongside, k_combine follows and takes the logs of log P
         forward_utt<L, false>(N, u, i, A, b, off, alpha, scale, sinv, lognorm, loglik, sink, only == 0);
