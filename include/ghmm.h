@@ -200,7 +200,9 @@ double *ghmm_stats_device_ptr(ghmm_stats *s);
 int ghmm_stats_download(ghmm_ctx *ctx, ghmm_stats *s, double *host);
 /* the two numbers the EM driver's stopping rule reads every iteration (TF:318-325):
  * out[0] = sum of log P over the utterances (`probab`), out[1] = utterance count
- * (`exemplar_number`) — a 16-byte download instead of the whole vector */
+ * (`exemplar_number`) — a 16-byte download instead of the whole vector; straight behind an
+ * E-step into a vector the library owns, a poll of pinned host memory the reduction kernel wrote
+ * (returns as soon as the two numbers exist: the stream is NOT drained) */
 int ghmm_stats_loglik(ghmm_ctx *ctx, ghmm_stats *s, double out[2]);
 int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *host);
 

@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <chrono>
+#include <cstring>
 #include "ghmm_kernels.hpp"
 #include "ghmm_mfma.hpp"
 #include "ghmm_pair.hpp"
@@ -87,6 +89,11 @@ struct ghmm_ctx {
     // milliseconds, a training job creates its model inside the time a user waits for.
     int *hflag_page = nullptr, *hflag_page_dev = nullptr;
     unsigned long long hflag_used = 0;
+    // a second such page: 32-byte mailboxes (log P, utterances, sequence) of the context's statistics
+    // vectors, written by k_reduce_all, polled by ghmm_stats_loglik
+    long long *mbox_page = nullptr, *mbox_page_dev = nullptr;
+    unsigned long long mbox_used = 0;
+    long long mbox_seq = 0;
     bool loglik_pieces = false; // log P of the last E-step is in lpart / logk, loglik[] not assembled
     int lp_nch = 0;             // chunks per utterance of those pieces
     bool own_bwd_done = false; // k_scan_pair ran the backward direction for the current alpha
@@ -183,6 +190,11 @@ struct ghmm_stats {
     double *v = nullptr;
     bool own = false;
     size_t n = 0;
+    // mailbox of (log P, utterances) in the context's pinned page (own vectors only: a wrapped one
+    // can change behind the library's back); valid while nothing has rewritten v since k_reduce_all
+    int mbox_slot = -1;
+    long long mbox_expect = 0;
+    bool mbox_valid = false;
 };
 
 static const char *k_names[GHMM_K_COUNT] = {"emission", "forward", "backward", "mixstats",
@@ -390,6 +402,7 @@ extern "C" void ghmm_ctx_destroy(ghmm_ctx *ctx)
     for (double *p : ctx->post_s)
         if (p) (void)hipFree(p);
     if (ctx->hflag_page) (void)hipHostFree(ctx->hflag_page);
+    if (ctx->mbox_page) (void)hipHostFree(ctx->mbox_page);
     for (int k = 0; k < 2; k++) {
         if (ctx->pin[k]) (void)hipHostFree(ctx->pin[k]);
         if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
@@ -879,6 +892,26 @@ extern "C" int ghmm_stats_create(ghmm_ctx *ctx, int N, int M, int D, ghmm_stats 
         ghmm_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
         return GHMM_ERR_HIP;
     }
+    // a mailbox slot (64 per context; without one ghmm_stats_loglik copies and waits as before)
+    if (!ctx->mbox_page) {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            memset(hp, 0, 4096);
+            ctx->mbox_page = (long long *)hp;
+            ctx->mbox_page_dev = (long long *)dp;
+        } else if (hp) {
+            (void)hipHostFree(hp);
+        }
+    }
+    if (ctx->mbox_page) {
+        int slot = 0;
+        while (slot < 64 && ((ctx->mbox_used >> slot) & 1ull)) slot++;
+        if (slot < 64) {
+            ctx->mbox_used |= 1ull << slot;
+            s->mbox_slot = slot;
+        }
+    }
     *out = s;
     return GHMM_OK;
 }
@@ -906,6 +939,7 @@ extern "C" void ghmm_stats_destroy(ghmm_ctx *ctx, ghmm_stats *s)
         (void)hipStreamSynchronize(ctx->stream);
     }
     if (s->own && s->v) (void)hipFree(s->v);
+    if (ctx && s->mbox_slot >= 0) ctx->mbox_used &= ~(1ull << s->mbox_slot);
     delete s;
 }
 
@@ -926,7 +960,24 @@ extern "C" int ghmm_stats_loglik(ghmm_ctx *ctx, ghmm_stats *s, double out[2])
     int rc = use(ctx);
     if (rc) return rc;
     ARG_CHECK(s && out, "null argument");
-    // loglik and n_utt are the last two doubles of the vector (layout in ghmm.h)
+    // loglik and n_utt are the last two doubles of the vector (layout in ghmm.h).  Straight behind an
+    // E-step they are also in the vector's mailbox in pinned memory, a sequence number behind them:
+    // polling that costs the kernel's own latency, a 16-byte copy and a stream wait ~0.1 ms more.
+    if (s->mbox_valid && s->mbox_slot >= 0 && ctx->mbox_page) {
+        volatile long long *mb = ctx->mbox_page + 4 * s->mbox_slot;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+            if (__atomic_load_n(mb + 2, __ATOMIC_ACQUIRE) == s->mbox_expect) {
+                long long a = mb[0], b = mb[1];
+                memcpy(&out[0], &a, 8);
+                memcpy(&out[1], &b, 8);
+                return GHMM_OK;
+            }
+            if ((spins & 1023u) == 1023u &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+                break; // (a launch that failed, a device far behind: the copy below waits for it)
+        }
+    }
     HIP_TRY(hipMemcpyAsync(out, s->v + (s->n - 2), 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
@@ -937,6 +988,7 @@ extern "C" int ghmm_stats_upload(ghmm_ctx *ctx, ghmm_stats *s, const double *hos
     int rc = use(ctx);
     if (rc) return rc;
     ARG_CHECK(s && host, "null argument");
+    s->mbox_valid = false;
     HIP_TRY(hipMemcpyAsync(s->v, host, s->n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(stream_sync(ctx));
     return GHMM_OK;
@@ -1613,6 +1665,10 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         ra.kappa = 2.0 * 1.1102230246251565e-16 * ((double)c->F / (double)(ctx->cus * MSM_WAVES) + 2.0 * ctx->cus + 64.0);
         ra.part_xi = ctx->part_xi; ra.part_dena = ctx->part_dena; ra.part_denc = ctx->part_denc;
         ra.loglik = ctx->loglik; ra.stats = s->v;
+        ra.mbox = (s->mbox_slot >= 0 && ctx->mbox_page_dev) ? ctx->mbox_page_dev + 4 * s->mbox_slot : nullptr;
+        ra.mbox_seq = ++ctx->mbox_seq;
+        s->mbox_expect = ra.mbox_seq;
+        s->mbox_valid = ra.mbox != nullptr;
         if (mfma && c->F == 0) ra.P1 = 0; // nothing accumulated: every sum is empty
         const int NGb = ra.Pm > 0 ? m->NT * 16 : G;
         kscope ks(ctx, GHMM_K_REDUCE);
@@ -2310,6 +2366,7 @@ extern "C" int ghmm_stats_allreduce(ghmm_ctx *ctx, ghmm_stats *s, ghmm_comm *cm)
     ARG_CHECK(cm->device == ctx->device, "communicator and context are on different devices");
     const rccl_api *api = rccl_or_error();
     if (!api) return GHMM_ERR_UNSUPPORTED;
+    s->mbox_valid = false; // (the sum over ranks replaces what k_reduce_all left in the mailbox)
     // in place, on the stream that carries the E-step before it and the M-step after it
     RCCL_TRY(api, api->AllReduce(s->v, s->v, s->n, ncclDouble, ncclSum, cm->comm, ctx->stream));
     return GHMM_OK;

@@ -963,6 +963,10 @@ __device__ inline double block_sum_fixed(double v, double *sh)
 
 struct reduce_args {
     int N, M, D, U, delta;
+    // host-visible copy of (log P, utterances) + a sequence number behind them (pinned, fine-grained
+    // memory: the trainer's stopping rule polls it instead of copying and waiting); nullptr: none
+    long long *mbox;
+    long long mbox_seq;
     int S; // slots of the utterance partials: one per utterance, or one per (utterance, chunk)
     // vector-ALU partials (vec == 0: k_mixstats was not launched; a class-2 Gaussian is then
     // recomputed here, exactly)
@@ -1192,6 +1196,12 @@ __global__ void __launch_bounds__(RD_THREADS) k_reduce_all(reduce_args a)
         if (tid == 0) {
             num_var[(size_t)G * D] = v;            // loglik
             num_var[(size_t)G * D + 1] = (double)U; // n_utt
+            if (a.mbox) {
+                __hip_atomic_store(a.mbox, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.mbox + 1, __double_as_longlong((double)U), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.mbox + 2, a.mbox_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     } else if (a.otile) {
         // offset of the expanded form for tile t of the NEXT model: the mean of the tile's worst-
