@@ -1561,7 +1561,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
     int rc;
     // frame-block partials: enough blocks to fill the chip a few times over, few
     // enough that the partial sums stay small next to the frame data
-    long long P = ctx->partials > 0 ? ctx->partials : (2LL * ctx->cus + NB - 1) / NB;
+    long long P = ctx->partials > 0 ? ctx->partials : (4LL * ctx->cus + NB - 1) / NB; // (4 blocks per CU: 0.70 -> 0.41 ms at configs[1] against 2)
     if (mfma && ctx->partials <= 0 && G <= MS_MAXG) {
         // behind the matrix-core kernel this one only sees the few ill-conditioned Gaussians
         // (one block of elements): parallelism has to come from the frame axis
@@ -1814,6 +1814,18 @@ extern "C" int ghmm_mstep(ghmm_ctx *ctx, ghmm_model *m, ghmm_stats *s)
 // creating_initial_model (TF:732-1317): distance / accumulation passes on the device (hard
 // statistics through the vector-ALU statistics kernel: direct (x - mean)^2, no expanded
 // form), cell bookkeeping on the host exactly as the reference orders it.
+// new means, everything else as last set (the k-means passes of ghmm_model_init: one copy instead of five)
+static int model_set_means(ghmm_ctx *ctx, ghmm_model *m, const double *mean)
+{
+    if (ctx->last_m == m) ctx->last_m = nullptr;
+    HIP_TRY(hipMemcpyAsync(m->mean, mean, (size_t)m->N * m->M * m->D * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(stream_sync(ctx)); // (pageable host memory, see ghmm_model_set)
+    m->epoch++;
+    m->vec_until = m->epoch + VEC_WINDOW;
+    m->prep_mark = ++ctx->launch_mark;
+    return model_prepare(ctx, m, true);
+}
+
 extern "C" int ghmm_model_init(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c)
 {
     return ghmm_model_init_comm(ctx, m, c, nullptr);
@@ -1856,9 +1868,13 @@ extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c
     // their distortions: they run on the context's tier (matrix-core sums, 0.08 ms a pass).  The
     // last pass gives the model's variances: direct-form statistics (x - mean)^2 on the vector
     // ALU, like the reference takes them (0.7 ms).
+    bool first_pass = true;
     auto pass = [&](int n_cells, bool exact) -> int {
         ctx->kernels = exact ? 1 : saved_kernels;
-        int r = ghmm_model_set(ctx, m, A.data(), cw.data(), cells.data(), ones.data(), det1.data());
+        // (only the cells' means change from pass to pass)
+        int r = first_pass ? ghmm_model_set(ctx, m, A.data(), cw.data(), cells.data(), ones.data(), det1.data())
+                           : model_set_means(ctx, m, cells.data());
+        first_pass = false;
         if (r) return r;
         {
             kscope ks(ctx, GHMM_K_PREPARE);
