@@ -1918,6 +1918,53 @@ extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c
         ghmm_stats_destroy(ctx, st);
         return r;
     };
+    bool dev_done = false;
+    if (M <= INIT_MAXM) {
+        // The k-means rounds without a trip to the host: a pass leaves the cell sums in `st`,
+        // k_init_cells turns them into the next pass's means on the device (same operations, same
+        // order as the host loop below, which stays for wider mixtures), the matrix-core form of the
+        // new means is prepared, the next pass is launched.  (Downloading the sums and uploading
+        // the means was ~80 us of round trips per pass, eleven passes at eight mixtures.)
+        auto dev_pass = [&](int n_cells, int do_split, bool first) -> int {
+            int r;
+            if (first) {
+                if ((r = ghmm_model_set(ctx, m, A.data(), cw.data(), cells.data(), ones.data(), det1.data()))) return r;
+            } else {
+                if (ctx->last_m == m) ctx->last_m = nullptr;
+                m->epoch++;
+                m->vec_until = m->epoch + VEC_WINDOW;
+                m->prep_mark = ++ctx->launch_mark;
+                if ((r = model_prepare(ctx, m, true))) return r;
+            }
+            {
+                kscope ks(ctx, GHMM_K_PREPARE);
+                int FR = IC_FRAMES;
+                while (FR > 1 && (size_t)FR * (D | 1) * sizeof(double) > 48 * 1024) FR /= 2;
+                hipLaunchKernelGGL(k_init_classify, dim3((unsigned)((c->F + FR - 1) / FR)), dim3(256),
+                                   (size_t)FR * (D | 1) * sizeof(double), ctx->stream, N, M, D, n_cells,
+                                   c->U, c->F, FR, c->X, c->off, m->mean, ctx->gamma, ctx->post);
+            }
+            if ((r = launch_ok("k_init_classify")) || (r = run_accumulate(ctx, m, c, st))) return r;
+            if (comm && (r = ghmm_stats_allreduce(ctx, st, comm))) return r;
+            hipLaunchKernelGGL(k_init_cells, dim3((unsigned)N), dim3(64), 0, ctx->stream, N, M, D, n_cells,
+                               do_split, first ? 1 : 0, st->v, m->mean);
+            return launch_ok("k_init_cells");
+        };
+        ctx->kernels = saved_kernels;
+        if ((rc = dev_pass(1, 1 < M ? 1 : 0, true))) return finish(rc);
+        int nc = 1;
+        while (nc < M) {
+            nc = (2 * nc < M) ? 2 * nc : M;
+            for (int it = 0; it < 3; it++)
+                if ((rc = dev_pass(nc, (it == 2 && nc < M) ? 1 : 0, false))) return finish(rc);
+        }
+        // the final means, for the last (direct-form) pass's bookkeeping below
+        HIP_TRY(hipMemcpyAsync(cells.data(), m->mean, (size_t)G * D * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(stream_sync(ctx));
+        first_pass = false;
+        dev_done = true;
+    }
+    if (!dev_done) {
     // one cell per state: the mean of the state's frames
     if ((rc = pass(1, false))) return finish(rc);
     for (int k = 0; k < N; k++)
@@ -1951,6 +1998,7 @@ extern "C" int ghmm_model_init_comm(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c
             }
         }
     }
+    } // (!dev_done)
     // per-cell variance around the final means and cell weights (TF:883-933)
     if ((rc = pass(M, true))) return finish(rc);
     std::vector<double> iv((size_t)G * D), dt((size_t)G);

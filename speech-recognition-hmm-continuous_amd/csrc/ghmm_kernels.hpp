@@ -1355,6 +1355,72 @@ k_mstep(int N, int M, int D, const double *__restrict__ stats, double norm2pi,
     mstep_state(N, M, D, stats, norm2pi, A, c, mean, inv_var, det, wk, logwk, logA, lds_doubles, vs, delta);
 }
 
+// The cell bookkeeping between two k-means passes of the initial model (TF:1043-1270), on the device:
+// new means = cell sums / counts, empty cells re-seeded from the cells of largest distortion, and
+// (do_split) the split that opens the next round — the same operations in the same order as the
+// host loop of ghmm_model_init_comm, block = state, thread = coefficient (every thread walks the
+// same order of cells).  M <= INIT_MAXM.
+constexpr int INIT_MAXM = 64;
+__global__ void __launch_bounds__(64)
+k_init_cells(int N, int M, int D, int n_cells, int do_split, int first, const double *__restrict__ stats,
+             double *__restrict__ cells)
+{
+    __shared__ double dist[INIT_MAXM];
+    __shared__ int idx[INIT_MAXM];
+    const int k = blockIdx.x, tid = threadIdx.x, G = N * M;
+    const double *num_c = stats + (size_t)N * N + 2 * (size_t)N, *num_mu = num_c + G, *num_var = num_mu + (size_t)G * D;
+    double *ck = cells + (size_t)k * M * D;
+    for (int j = tid; j < M; j += 64) {
+        double d = 0.0;
+        for (int l = 0; l < D; l++) d += num_var[((size_t)k * M + j) * D + l];
+        dist[j] = d;
+    }
+    __syncthreads();
+    // indices by decreasing key, adjacent-swap passes with strict '<' (TF:1289-1315)
+    auto order_desc = [&](int n) {
+        if (tid == 0) {
+            for (int i = 0; i < n; i++) idx[i] = i;
+            bool done = false;
+            while (!done) {
+                done = true;
+                for (int i = 0; i < n - 1; i++)
+                    if (dist[idx[i]] < dist[idx[i + 1]]) {
+                        const int t = idx[i];
+                        idx[i] = idx[i + 1];
+                        idx[i + 1] = t;
+                        done = false;
+                    }
+            }
+        }
+        __syncthreads();
+    };
+    auto split_cell = [&](int from, int to) { // TF:1138
+        for (int l = tid; l < D; l += 64) {
+            const double v = ck[(size_t)from * D + l];
+            ck[(size_t)to * D + l] = v * 1.005;
+            ck[(size_t)from * D + l] = v * 0.995;
+        }
+    };
+    for (int j = 0; j < n_cells; j++)
+        for (int l = tid; l < D; l += 64)
+            ck[(size_t)j * D + l] = num_mu[((size_t)k * M + j) * D + l] / num_c[(size_t)k * M + j];
+    if (!first) { // empty cells are re-seeded from the cells with the largest distortion (TF:1236-1270)
+        order_desc(n_cells);
+        int i = 0;
+        for (int j = 0; j < n_cells; j++)
+            if (num_c[(size_t)k * M + j] == 0.0) split_cell(idx[i++], j); // (a thread only ever touches its own coefficients)
+    }
+    if (do_split) {
+        if (2 * n_cells < M) {
+            for (int i = 0; i < n_cells; i++) split_cell(i, n_cells + i);
+        } else {
+            order_desc(n_cells);
+            for (int i = 0; i < M - n_cells; i++) split_cell(idx[i], n_cells + i);
+        }
+    }
+}
+
+
 // --------------------------------------------------------------- init model
 // creating_initial_model (TF:732-1317) on the device.  Its k-means passes are "hard"
 // statistics: with gamma_t = one-hot(state that owns frame t under the uniform
