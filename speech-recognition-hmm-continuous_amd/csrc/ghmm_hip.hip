@@ -194,6 +194,7 @@ struct ghmm_stats {
     // can change behind the library's back); valid while nothing has rewritten v since k_reduce_all
     int mbox_slot = -1;
     long long mbox_expect = 0;
+    long long mbox_mark = 0; // ctx->launch_mark when the k_reduce_all that fills it was enqueued
     bool mbox_valid = false;
 };
 
@@ -971,6 +972,9 @@ extern "C" int ghmm_stats_loglik(ghmm_ctx *ctx, ghmm_stats *s, double out[2])
                 long long a = mb[0], b = mb[1];
                 memcpy(&out[0], &a, 8);
                 memcpy(&out[1], &b, 8);
+                // everything enqueued before that k_reduce_all has completed: as good as a wait for
+                // the host's view of the models' flags (run_accumulate's exact decision)
+                if (s->mbox_mark > ctx->sync_mark) ctx->sync_mark = s->mbox_mark;
                 return GHMM_OK;
             }
             if ((spins & 1023u) == 1023u &&
@@ -1668,6 +1672,7 @@ static int run_accumulate(ghmm_ctx *ctx, ghmm_model *m, ghmm_corpus *c, ghmm_sta
         ra.mbox = (s->mbox_slot >= 0 && ctx->mbox_page_dev) ? ctx->mbox_page_dev + 4 * s->mbox_slot : nullptr;
         ra.mbox_seq = ++ctx->mbox_seq;
         s->mbox_expect = ra.mbox_seq;
+        s->mbox_mark = ctx->launch_mark;
         s->mbox_valid = ra.mbox != nullptr;
         if (mfma && c->F == 0) ra.P1 = 0; // nothing accumulated: every sum is empty
         const int NGb = ra.Pm > 0 ? m->NT * 16 : G;
